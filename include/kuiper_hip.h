@@ -1,0 +1,199 @@
+/*
+ * kuiper_hip.h — C-ABI of libkuiper_hip.so: the MI355X (gfx950) decode path that drops in
+ * behind KuiperLLama's kernel-function-pointer interface
+ *     kuiper/source/op/kernels/kernels_interface.h:6-68   (typedefs + get_*_kernel getters)
+ * and, one level up, behind model::LLama2Model / model::Qwen2Model
+ *     kuiper/include/model/model.h:20-56, kuiper/source/model/llama3.cpp:107-167,733-745.
+ *
+ * Conventions
+ *   - every function returns int: 0 = success, >0 = a hipError_t, <0 = KH_ERR_* below.
+ *     Nothing aborts (the reference CHECK/LOG(FATAL)s; a C-ABI must not).
+ *   - all tensor pointers are DEVICE pointers unless a parameter is named h_* / host.
+ *   - tensors are dense row-major fp32 (int8 for quantised weights), exactly the layouts of
+ *     the reference (weights [K rows, M cols]; KV cache [layer, seq_len, kv_dim]).
+ *   - `stream` is a hipStream_t passed as void* (the reference passes `void* stream` /
+ *     CudaConfig::stream the same way, kuiper/include/base/cuda_config.h:6-13).
+ *     Launches are asynchronous on that stream, never allocate, never synchronise, and are
+ *     hipGraph-capturable — which is why positions/tokens can be given as DEVICE scalars
+ *     (the reference reads `pos` on the host: cuda/rope_kernel.cu:157, op/mha.cpp:33).
+ *   - callee never takes ownership of caller memory.
+ */
+#ifndef KUIPER_HIP_H
+#define KUIPER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KH_VERSION 100 /* 0.1.0 */
+
+enum {
+  KH_OK = 0,
+  KH_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, size mismatch */
+  KH_ERR_UNSUPPORTED = -2, /* e.g. int8 + tied classifier (broken in the reference too) */
+  KH_ERR_IO = -3,          /* file open/map failure (reference: error::PathNotValid) */
+  KH_ERR_FORMAT = -4,      /* malformed .bin (reference: error::ModelParseError) */
+  KH_ERR_NO_DEVICE = -5,
+  KH_ERR_RANGE = -6        /* token / position out of range */
+};
+const char* kh_error_string(int code);
+int kh_version(void);
+/* number of HIP devices visible; <0 on error */
+int kh_device_count(void);
+
+enum { KH_ROPE_INTERLEAVED = 0, KH_ROPE_HALF = 1 };
+enum { KH_FAMILY_LLAMA = 0, KH_FAMILY_QWEN2 = 1 };
+
+/* ============================ operator level ==========================================
+ * One entry point per reference kernel typedef (kernels_interface.h). */
+
+/* AddKernel (kernels_interface.h:6-7; cuda/add_kernel.cu:14-32): out = in1 + in2 */
+int kh_add_f32(const float* in1, const float* in2, float* out, int32_t n, void* stream);
+
+/* MatmulKernel (kernels_interface.h:9-10; cuda/matmul_kernel.cu:89-109,
+ * cpu/matmul_kernel.cpp:5-41): y[K] = (W[K,M] . x[M]) * scale.
+ * (The reference CUDA path ignores `scale`, the CPU path honours it; honoured here.) */
+int kh_matmul_f32(const float* x, const float* w, float* y, int32_t M, int32_t K, float scale,
+                  void* stream);
+
+/* MatmulKernelQuant (kernels_interface.h:12-14; cuda/matmul_kernel.cu:56-87,111-134):
+ * y[p] = sum_i x[i] * scales[(p*M+i)/group_size] * float(w8[p*M+i]) */
+int kh_matmul_q8(const float* x, const int8_t* w8, const float* scales, int32_t group_size,
+                 float* y, int32_t M, int32_t K, void* stream);
+
+/* EmbeddingKernel (kernels_interface.h:16-17; cuda/emb_kernel.cu:3-48):
+ * out[t,:] = W[tokens[t],:].  tokens is a DEVICE int32 array (the reference uploads a host
+ * tensor per call, emb_kernel.cu:25-29; the host adapter does that upload).  Rows whose
+ * token is outside [0, vocab) are left untouched. */
+int kh_embedding_f32(const int32_t* tokens, int32_t n_tokens, const float* w, float* out,
+                     int32_t dim, int32_t vocab, void* stream);
+
+/* SwigluKernel (kernels_interface.h:19-20; cuda/swiglu_kernel.cu:4-47):
+ * out = a*sigmoid(a) * b ; out may alias a (llama3.cpp:708). */
+int kh_swiglu_f32(const float* a, const float* b, float* out, int32_t n, void* stream);
+
+/* RMSNormKernel (kernels_interface.h:30-31; cuda/rmsnorm_kernel.cu:5-78,
+ * cpu/rmsnorm_kernel.cpp:4-33): out = w * (x / sqrt(mean(x^2)+eps)); out may alias x.
+ * eps is a compile-time #ifdef in the reference (1e-5 / 1e-6 QWEN2). */
+int kh_rmsnorm_f32(const float* x, const float* w, float* out, int32_t n, float eps,
+                   void* stream);
+
+/* RoPEKernel (kernels_interface.h:33-36; cuda/rope_kernel.cu:5-36,51-82,104-122,153-170):
+ * in-place rotation of q[dim] and k[kv_dim] with cached sin/cos row `pos`.
+ * mode selects what the reference picks with LLAMA3_SUPPORT/QWEN2_SUPPORT (half) or
+ * neither (interleaved).  Position = *d_pos if d_pos != NULL else pos. */
+int kh_rope_f32(int32_t dim, int32_t kv_dim, int32_t head_size, float* q, float* k,
+                const int32_t* d_pos, int32_t pos, const float* sin_cache,
+                const float* cos_cache, int32_t mode, void* stream);
+
+/* sin_cos_cache_calc_cu (cuda/rope_kernel.cuh:9-10; cpu/rope_kernel.cpp:4-16):
+ * cache[pos*hs + d] = sin/cos(float(pos) * (1/pow(theta, d/hs))) for d < head_size. */
+int kh_sincos_cache_f32(int32_t head_size, int32_t max_seq_len, float theta, float* sin_cache,
+                        float* cos_cache, void* stream);
+
+/* MHAKernel (kernels_interface.h:22-28; cuda/mha_kernel.cu:47-130, cpu/mha_kernel.cpp:5-61).
+ * Decode attention for one query token over the contiguous KV cache; softmax probabilities
+ * are left in score[head, 0..pos] like the reference.  Position = *d_pos or pos. */
+int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num, int32_t layer_index,
+               int32_t seq_len, int32_t kv_dim, int32_t kv_mul, int32_t head_size,
+               float* mha_out, const float* q, float* score, const float* kcache,
+               const float* vcache, void* stream);
+
+/* argmax_kernel_cu (cuda/argmax_kernel.cuh:4; argmax_sampler.cpp:5-13): index of the first
+ * maximum.  Device-result form (graph-capturable) and host-result form (synchronises the
+ * stream, like the reference's D2H copy at argmax_kernel.cu:84). */
+int kh_argmax_f32(const float* logits, int64_t n, int32_t* d_out_index, void* stream);
+int kh_argmax_f32_host(const float* logits, int64_t n, int64_t* h_out_index, void* stream);
+
+/* CPU-only helpers of the reference (kernels_interface.h:38-46), provided on device so the
+ * op set is closed: softmax in place, x *= scale, out += sum_t scale[t]*value[t*stride..] */
+int kh_softmax_f32(float* x, int32_t n, void* stream);
+int kh_scale_f32(float scale, float* x, int32_t n, void* stream);
+int kh_scale_sum_f32(const float* value, const float* scale, float* out, int32_t pos,
+                     int32_t size, int32_t stride, void* stream);
+
+/* ============================ model level ==============================================
+ * Replaces model::LLama2Model / Qwen2Model for the decode path: .bin image -> HBM arena,
+ * per-token forward, greedy generate loop captured in a hipGraph. */
+typedef struct kh_model kh_model;
+
+typedef struct kh_model_opts {
+  int32_t family;      /* KH_FAMILY_* : weight layout (llama3.cpp:290-423 / qwen2.cpp) */
+  int32_t is_quant;    /* int8 group-quantised image (tools/export.py version 3) */
+  int32_t rope_mode;   /* KH_ROPE_* */
+  float rope_theta;    /* 10000 / 500000 (LLAMA3) / 1000000 (QWEN2) in the reference */
+  float rms_eps;       /* 1e-5 / 1e-6 (QWEN2) */
+  int32_t max_seq_len; /* rows of KV cache + sin/cos to allocate; 0 = header seq_len */
+  int32_t device;      /* HIP device ordinal (reference: cudaSetDevice(0)) */
+  int32_t flags;       /* reserved, 0 */
+} kh_model_opts;
+
+typedef struct kh_config {
+  int32_t dim, hidden_dim, layer_num, head_num, kv_head_num, vocab_size, seq_len;
+  int32_t kv_dim, kv_mul, head_size, is_shared_weight, is_quant, group_size;
+  int32_t family, rope_mode, cache_len;
+  float rope_theta, rms_eps;
+  int64_t weight_bytes; /* bytes of the weight arena resident in HBM */
+} kh_config;
+
+/* Model::read_model_file + init (model.cpp:41-123, llama3.cpp:107-145) */
+int kh_model_create_from_file(const char* path, const kh_model_opts* opts, kh_model** out);
+/* same, from the bytes of a .bin file already in host memory (header included) */
+int kh_model_create_from_host_image(const void* h_image, size_t nbytes,
+                                    const kh_model_opts* opts, kh_model** out);
+/* weights already resident in HBM: h_header = the 7 (fp32) or 8 (int8) header ints,
+ * d_weight_data = the file bytes AFTER the header, 16-byte aligned, not owned
+ * (the reference's "external buffer", layer.cpp:190-202). */
+int kh_model_create_from_device_weights(const int32_t* h_header, const void* d_weight_data,
+                                        size_t weight_nbytes, const kh_model_opts* opts,
+                                        kh_model** out);
+void kh_model_destroy(kh_model* m);
+int kh_model_get_config(const kh_model* m, kh_config* out);
+void* kh_model_stream(kh_model* m); /* the model's hipStream_t */
+
+enum {
+  KH_EXEC_GRAPH = 0,   /* fused kernels, whole step replayed as one hipGraph */
+  KH_EXEC_FUSED = 1,   /* fused kernels, eager launches */
+  KH_EXEC_UNFUSED = 2  /* one launch per reference kernel, in the reference's order
+                          (llama3.cpp:147-167): the literal drop-in sequence */
+};
+
+/* Model::predict (llama3.cpp:642-650): embedding of `token` -> forward at `pos` ->
+ * argmax unless is_prompt.  *h_next receives the token (or -1 when is_prompt).
+ * Synchronises the stream. exec: KH_EXEC_FUSED or KH_EXEC_UNFUSED. */
+int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t is_prompt, int32_t exec,
+                     int32_t* h_next);
+/* copy the last logits (kForwardOutput) to host */
+int kh_model_get_logits(kh_model* m, float* h_logits);
+/* device pointers of the KV cache [layer, cache_len, kv_dim] (tests) */
+int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache);
+/* copy rows [row0, row0+nrows) of one layer's K and V cache to host (tests) */
+int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows, float* h_k,
+                     float* h_v);
+
+/* demo/main.cpp:5-47 generate(): prompt fed one token per step without sampling, then
+ * greedy decode, `total_steps` forward passes in total; h_words receives the reference's
+ * `words` vector.  No stop-token check (tokeniser is out of scope).  *h_elapsed_ms = wall
+ * time of the step loop measured with HIP events on the model stream. */
+int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
+                      int32_t total_steps, int32_t exec, int32_t* h_words, int32_t* n_words,
+                      float* h_elapsed_ms);
+
+/* Per-kernel-class timing of the fused step with HIP events (eager launches, one event
+ * between every kernel).  n_steps decode steps starting at position start_pos (KV rows
+ * below start_pos must already exist).  Writes avg microseconds per launch for each
+ * class into h_avg_us[KH_NUM_KCLASS] and launches-per-step into h_count. */
+enum {
+  KH_K_QKV = 0, KH_K_ATTN = 1, KH_K_WO = 2, KH_K_FFN13 = 3, KH_K_W2 = 4, KH_K_CLS = 5,
+  KH_K_SAMPLE = 6, KH_NUM_KCLASS = 7
+};
+int kh_model_profile_step(kh_model* m, int32_t start_pos, int32_t n_steps, float* h_avg_us,
+                          int32_t* h_count);
+const char* kh_kclass_name(int kclass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KUIPER_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libkuiper_hip.so (include/kuiper_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module raises, and
+any op called without a GPU returns the library's error code as an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libkuiper_hip.so")
+
+# every symbol include/kuiper_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "kh_error_string", "kh_version", "kh_device_count",
+    "kh_add_f32", "kh_matmul_f32", "kh_matmul_q8", "kh_embedding_f32", "kh_swiglu_f32",
+    "kh_rmsnorm_f32", "kh_rope_f32", "kh_sincos_cache_f32", "kh_mha_f32", "kh_argmax_f32",
+    "kh_argmax_f32_host", "kh_softmax_f32", "kh_scale_f32", "kh_scale_sum_f32",
+    "kh_model_create_from_file", "kh_model_create_from_host_image",
+    "kh_model_create_from_device_weights", "kh_model_destroy", "kh_model_get_config",
+    "kh_model_stream", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
+    "kh_model_generate", "kh_model_profile_step", "kh_kclass_name",
+]
+
+KH_EXEC_GRAPH, KH_EXEC_FUSED, KH_EXEC_UNFUSED = 0, 1, 2
+KH_NUM_KCLASS = 7
+
+
+class KhError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        self.code = code
+        super().__init__(f"{what}: kh error {code} ({error_string(code)})")
+
+
+class ModelOpts(C.Structure):
+    _fields_ = [("family", C.c_int32), ("is_quant", C.c_int32), ("rope_mode", C.c_int32),
+                ("rope_theta", C.c_float), ("rms_eps", C.c_float), ("max_seq_len", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim", "hidden_dim", "layer_num", "head_num", "kv_head_num", "vocab_size", "seq_len",
+        "kv_dim", "kv_mul", "head_size", "is_shared_weight", "is_quant", "group_size", "family",
+        "rope_mode", "cache_len")] + [("rope_theta", C.c_float), ("rms_eps", C.c_float),
+                                      ("weight_bytes", C.c_int64)]
+
+
+_lib: Optional[C.CDLL] = None
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch first: its wheel bundles the HIP runtime (libamdhip64.so.7); loading it before our
+    # library makes both bind to ONE runtime, so torch-owned device pointers/streams are valid
+    # inside libkuiper_hip.so.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m kuiperllama_amd.build` "
+            "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    L.kh_error_string.argtypes = [C.c_int]
+    L.kh_error_string.restype = C.c_char_p
+    L.kh_version.restype = C.c_int
+    L.kh_device_count.restype = C.c_int
+    L.kh_add_f32.argtypes = [_vp, _vp, _vp, _i32, _vp]
+    L.kh_matmul_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _f32, _vp]
+    L.kh_matmul_q8.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]
+    L.kh_embedding_f32.argtypes = [_vp, _i32, _vp, _vp, _i32, _i32, _vp]
+    L.kh_swiglu_f32.argtypes = [_vp, _vp, _vp, _i32, _vp]
+    L.kh_rmsnorm_f32.argtypes = [_vp, _vp, _vp, _i32, _f32, _vp]
+    L.kh_rope_f32.argtypes = [_i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]
+    L.kh_sincos_cache_f32.argtypes = [_i32, _i32, _f32, _vp, _vp, _vp]
+    L.kh_mha_f32.argtypes = [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                             _vp, _vp]
+    L.kh_argmax_f32.argtypes = [_vp, _i64, _vp, _vp]
+    L.kh_argmax_f32_host.argtypes = [_vp, _i64, C.POINTER(_i64), _vp]
+    L.kh_softmax_f32.argtypes = [_vp, _i32, _vp]
+    L.kh_scale_f32.argtypes = [_f32, _vp, _i32, _vp]
+    L.kh_scale_sum_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _i32, _vp]
+    L.kh_model_create_from_file.argtypes = [C.c_char_p, C.POINTER(ModelOpts), C.POINTER(_vp)]
+    L.kh_model_create_from_host_image.argtypes = [_vp, C.c_size_t, C.POINTER(ModelOpts),
+                                                  C.POINTER(_vp)]
+    L.kh_model_create_from_device_weights.argtypes = [C.POINTER(_i32), _vp, C.c_size_t,
+                                                      C.POINTER(ModelOpts), C.POINTER(_vp)]
+    L.kh_model_destroy.argtypes = [_vp]
+    L.kh_model_destroy.restype = None
+    L.kh_model_get_config.argtypes = [_vp, C.POINTER(Config)]
+    L.kh_model_stream.argtypes = [_vp]
+    L.kh_model_stream.restype = _vp
+    L.kh_model_predict.argtypes = [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
+    L.kh_model_get_logits.argtypes = [_vp, _vp]
+    L.kh_model_get_kv.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]
+    L.kh_model_read_kv.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp]
+    L.kh_model_generate.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),
+                                    C.POINTER(_i32), C.POINTER(_f32)]
+    L.kh_model_profile_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32), C.POINTER(_i32)]
+    L.kh_kclass_name.argtypes = [C.c_int]
+    L.kh_kclass_name.restype = C.c_char_p
+    for name in EXPORTS:  # fail at load time, not at first call, if a symbol is missing
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def error_string(code: int) -> str:
+    return lib().kh_error_string(int(code)).decode()
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise KhError(int(code), what)

@@ -1,0 +1,144 @@
+// kh_attn.h — single-query (decode) attention over the contiguous KV cache, one workgroup per
+// query head.  reference: cuda/mha_kernel.cu:47-110 (+ softmax_gpu :7-45), cpu/mha_kernel.cpp:5-61.
+//
+// KV layout is the reference's: cache[layer, t, kv_dim]; head h reads columns
+// (h/kv_mul)*hs .. +hs of every row t <= pos (row stride kv_dim floats).
+//
+// Mapping (wave64): G = pow2 >= hs/4 lanes cooperate on one timestep, each owning one float4
+// of the head vector, so a wave instruction reads 64/G whole K (or V) head-rows of hs*4
+// contiguous bytes — coalesced, unlike the reference's thread-per-timestep walk with a
+// kv_dim stride.  The q.k reduction is log2(G) shuffles.  Scores never touch global memory
+// (the reference round-trips them through kScoreStorage); they live in an LDS chunk of
+// KH_ATTN_TC timesteps, with flash-style running (max, sum) rescaling across chunks so any
+// pos < seq_len works.  P.V uses the same lane mapping: every lane accumulates its float4 of
+// the output over its timesteps, then timestep-groups are folded with shuffles + one LDS
+// exchange across the 4 waves.
+#pragma once
+#include "kh_common.h"
+
+#define KH_ATTN_TC 2048  // timesteps per LDS score chunk (8 KiB)
+
+static inline size_t attn_lds_bytes(int head_size) {
+  return (size_t)(KH_ATTN_TC + 8 + KH_WAVES_PER_WG * head_size) * sizeof(float);
+}
+
+// q_h: [hs] ; k_base/v_base: cache + layer offset + head column offset ; kv_stride = kv_dim.
+// out_h: [hs].  score_out (optional, global [>= pos+1]): receives the softmax probabilities like
+// the reference's score tensor.  smem: attn_lds_bytes(hs) bytes, 16-B aligned.
+__device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
+                                                 const float* __restrict__ k_base,
+                                                 const float* __restrict__ v_base, int kv_stride,
+                                                 int hs, int pos, float* __restrict__ out_h,
+                                                 float* __restrict__ score_out, float* smem) {
+  float* sc = smem;                    // [KH_ATTN_TC]
+  float* red = smem + KH_ATTN_TC;      // [8]
+  float* opart = red + 8;              // [4][hs]
+  const int tid = threadIdx.x;
+  const int hs4 = hs >> 2;
+  int G = 1;
+  while (G < hs4) G <<= 1;             // lanes per timestep (<= 64 since hs <= 256)
+  const int TPI = KH_WG / G;           // timesteps per workgroup iteration
+  const int tg = tid / G, dl = tid - tg * G;
+  const bool active = dl < hs4;
+  const int stride4 = kv_stride >> 2;
+  const f32x4* K4 = (const f32x4*)k_base;
+  const f32x4* V4 = (const f32x4*)v_base;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 q4 = active ? ((const f32x4*)q_h)[dl] : zero4;
+  const float scale = 1.0f / sqrtf((float)hs);   // cpu/mha_kernel.cpp:11
+  const int nT = pos + 1;
+  const bool single = nT <= KH_ATTN_TC;
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 o4 = zero4;
+
+  for (int t0 = 0; t0 < nT; t0 += KH_ATTN_TC) {
+    const int tc = min(KH_ATTN_TC, nT - t0);
+    // ---- scores: s[t] = (q . K[t]) * scale ---------------------------------------------
+    for (int tb = 0; tb < tc; tb += TPI * 4) {
+      f32x4 kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = tb + u * TPI + tg;
+        const int tt = t < tc ? t : tc - 1;
+        kv[u] = active ? K4[(size_t)(t0 + tt) * stride4 + dl] : zero4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = tb + u * TPI + tg;
+        float d = fma4(q4, kv[u], 0.f);
+        for (int off = G >> 1; off > 0; off >>= 1) d += __shfl_xor(d, off, KH_WAVE);
+        if (dl == 0 && t < tc) {
+          const float s = d * scale;
+          sc[t] = s;
+          if (score_out) score_out[t0 + t] = s;  // raw score; normalised in the last pass
+        }
+      }
+    }
+    __syncthreads();
+    // ---- running softmax statistics --------------------------------------------------------
+    float mx = -INFINITY;
+    for (int t = tid; t < tc; t += KH_WG) mx = fmaxf(mx, sc[t]);
+    mx = block_max(mx, red);
+    const float m_new = fmaxf(m_run, mx);
+    float s = 0.f;
+    for (int t = tid; t < tc; t += KH_WG) {
+      const float e = expf(sc[t] - m_new);
+      sc[t] = e;
+      s += e;
+    }
+    s = block_sum(s, red);
+    const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first chunk
+    l_run = l_run * alpha + s;
+    o4 = o4 * alpha;
+    m_run = m_new;
+    if (single) {
+      // one chunk: normalise BEFORE the weighted sum like cpu/softmax_kernel.cpp:13-14
+      for (int t = tid; t < tc; t += KH_WG) sc[t] = sc[t] / s;
+      __syncthreads();
+    }
+    // ---- o += sum_t p[t] * V[t] --------------------------------------------------------------
+    for (int tb = 0; tb < tc; tb += TPI * 4) {
+      f32x4 vv[4];
+      float p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = tb + u * TPI + tg;
+        const int tt = t < tc ? t : tc - 1;
+        vv[u] = active ? V4[(size_t)(t0 + tt) * stride4 + dl] : zero4;
+        p[u] = t < tc ? sc[tt] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o4.x = __builtin_fmaf(p[u], vv[u].x, o4.x);
+        o4.y = __builtin_fmaf(p[u], vv[u].y, o4.y);
+        o4.z = __builtin_fmaf(p[u], vv[u].z, o4.z);
+        o4.w = __builtin_fmaf(p[u], vv[u].w, o4.w);
+      }
+    }
+    __syncthreads();  // sc is rewritten by the next chunk
+  }
+
+  // ---- fold the timestep groups: lanes with equal dl inside a wave, then the 4 waves --------
+  for (int off = G; off < KH_WAVE; off <<= 1) {
+    o4.x += __shfl_xor(o4.x, off, KH_WAVE);
+    o4.y += __shfl_xor(o4.y, off, KH_WAVE);
+    o4.z += __shfl_xor(o4.z, off, KH_WAVE);
+    o4.w += __shfl_xor(o4.w, off, KH_WAVE);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (G <= KH_WAVE && lane < G && active) ((f32x4*)(opart + wave * hs))[dl] = o4;
+  __syncthreads();
+  if (tid < hs) {
+    float r = 0.f;
+    // when G == 256/TPI... every wave holds a partial for every d (TPI >= 4 <=> G <= 64)
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_PER_WG; ++w) r += opart[w * hs + tid];
+    out_h[tid] = single ? r : r / l_run;
+  }
+  if (score_out) {
+    // probabilities as the reference leaves them in the score tensor
+    const float inv_l = l_run;
+    for (int t = tid; t < nT; t += KH_WG) score_out[t] = expf(score_out[t] - m_run) / inv_l;
+  }
+}

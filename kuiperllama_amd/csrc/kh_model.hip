@@ -1,0 +1,837 @@
+// kh_model.hip — model level of the C-ABI: .bin image -> HBM arena, per-token forward,
+// greedy generate loop replayed as a hipGraph.  Replaces, for the decode path,
+//   model::Model::read_model_file / generate_model_infos   kuiper/source/model/model.cpp:41-151
+//   LLama2Model::create_param_layers / _quant_layers       kuiper/source/model/llama3.cpp:184-423
+//   Qwen2Model::create_param_layers (q/k/v bias)           kuiper/source/model/qwen2.cpp:290-426
+//   LLama2Model::init_mem / forward / predict              llama3.cpp:425-500, 147-167, 642-650
+//   generate()                                             demo/main.cpp:5-47
+// gfx950 only.  No CPU fallback: every path below launches HIP kernels.
+#include <fcntl.h>
+#include <math.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <new>
+#include <vector>
+
+#include "kh_fused.h"
+
+namespace {
+
+struct LayerW {
+  KhLin wq, wk, wv, wo, w1, w2, w3;
+  const float* att_norm;
+  const float* ffn_norm;
+};
+
+}  // namespace
+
+struct kh_model {
+  kh_config cfg{};
+  kh_model_opts opts{};
+  hipStream_t stream = nullptr;
+  // weights: one arena holding the .bin bytes after the header, in file order
+  char* arena = nullptr;
+  bool owns_arena = false;
+  size_t arena_bytes = 0;
+  std::vector<LayerW> layers;
+  const float* tok_emb = nullptr;
+  const float* final_norm = nullptr;
+  KhLin cls{};
+  int gshift = 0;
+  // activations / caches (llama3.cpp:425-500)
+  float *x = nullptr, *rms = nullptr, *q = nullptr, *att = nullptr, *h1 = nullptr,
+        *h3 = nullptr, *w2o = nullptr, *logits = nullptr, *score = nullptr, *kcache = nullptr,
+        *vcache = nullptr, *sin_cache = nullptr, *cos_cache = nullptr;
+  float* part_val = nullptr;
+  int32_t* part_idx = nullptr;
+  int nparts = 0;
+  int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
+          *d_words = nullptr;
+  int seq_cap = 0;  // capacity of d_forced / d_words
+  // launch geometry
+  int grid_qkv = 0, grid_wo = 0, grid_ffn = 0, grid_w2 = 0, grid_cls = 0;
+  int u_dim = 0, u_hid = 0;  // unroll choice for M = dim and M = hidden
+  // graph
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int pick_u(bool quant, int M) {
+  const int per_lane = quant ? (M / 16 + KH_WAVE - 1) / KH_WAVE : (M / 4 + KH_WAVE - 1) / KH_WAVE;
+  if (quant) return per_lane >= 3 ? 4 : 2;
+  return per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
+}
+
+int grid_for(int nitems) {
+  int g = (nitems + KH_WAVES_PER_WG - 1) / KH_WAVES_PER_WG;
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  return g;
+}
+
+int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+// ---- fused launches -------------------------------------------------------------------------
+#define KH_DISPATCH_U(KERNEL, QUANT, U, GRID, LDS, STREAM, ARGS)                              \
+  do {                                                                                        \
+    if (QUANT) {                                                                              \
+      if ((U) >= 4)                                                                           \
+        hipLaunchKernelGGL((KERNEL<true, 4>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);    \
+      else                                                                                    \
+        hipLaunchKernelGGL((KERNEL<true, 2>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);    \
+    } else {                                                                                  \
+      if ((U) >= 8)                                                                           \
+        hipLaunchKernelGGL((KERNEL<false, 8>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);   \
+      else if ((U) >= 4)                                                                      \
+        hipLaunchKernelGGL((KERNEL<false, 4>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);   \
+      else                                                                                    \
+        hipLaunchKernelGGL((KERNEL<false, 2>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);   \
+    }                                                                                         \
+  } while (0)
+
+void launch_qkv(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const LayerW& W = m->layers[l];
+  KhQkvArgs a;
+  a.x = m->x;
+  a.att_norm = W.att_norm;
+  a.wq = W.wq;
+  a.wk = W.wk;
+  a.wv = W.wv;
+  a.q_out = m->q;
+  a.kcache_layer = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.vcache_layer = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.d_pos = m->d_pos;
+  a.sin_cache = m->sin_cache;
+  a.cos_cache = m->cos_cache;
+  a.dim = c.dim;
+  a.kv_dim = c.kv_dim;
+  a.head_size = c.head_size;
+  a.rope_mode = c.rope_mode;
+  a.gshift = m->gshift;
+  a.eps = c.rms_eps;
+  const bool qn = c.is_quant;
+  KH_DISPATCH_U(k_qkv, qn, m->u_dim, m->grid_qkv, fused_lds_bytes(qn, c.dim), m->stream, a);
+}
+void launch_attn(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  KhAttnArgs a;
+  a.q = m->q;
+  a.kcache_layer = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.vcache_layer = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.out = m->att;
+  a.d_pos = m->d_pos;
+  a.kv_dim = c.kv_dim;
+  a.kv_mul = c.kv_mul;
+  a.head_size = c.head_size;
+  hipLaunchKernelGGL(k_attn, dim3(c.head_num), dim3(KH_WG), attn_lds_bytes(c.head_size),
+                     m->stream, a);
+}
+void launch_wo(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  KhGemvResArgs a;
+  a.vec = m->att;
+  a.w = m->layers[l].wo;
+  a.x = m->x;
+  a.M = c.dim;
+  a.K = c.dim;
+  a.gshift = m->gshift;
+  const bool qn = c.is_quant;
+  KH_DISPATCH_U(k_gemv_res, qn, m->u_dim, m->grid_wo, fused_lds_bytes(qn, c.dim), m->stream, a);
+}
+void launch_ffn13(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const LayerW& W = m->layers[l];
+  KhFfn13Args a;
+  a.x = m->x;
+  a.ffn_norm = W.ffn_norm;
+  a.w1 = W.w1;
+  a.w3 = W.w3;
+  a.h = m->h1;
+  a.dim = c.dim;
+  a.hidden = c.hidden_dim;
+  a.gshift = m->gshift;
+  a.eps = c.rms_eps;
+  const bool qn = c.is_quant;
+  KH_DISPATCH_U(k_ffn13, qn, m->u_dim, m->grid_ffn, fused_lds_bytes(qn, c.dim), m->stream, a);
+}
+void launch_w2(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  KhGemvResArgs a;
+  a.vec = m->h1;
+  a.w = m->layers[l].w2;
+  a.x = m->x;
+  a.M = c.hidden_dim;
+  a.K = c.dim;
+  a.gshift = m->gshift;
+  const bool qn = c.is_quant;
+  KH_DISPATCH_U(k_gemv_res, qn, m->u_hid, m->grid_w2, fused_lds_bytes(qn, c.hidden_dim),
+                m->stream, a);
+}
+void launch_cls(kh_model* m) {
+  const kh_config& c = m->cfg;
+  KhClsArgs a;
+  a.x = m->x;
+  a.final_norm = m->final_norm;
+  a.wcls = m->cls;
+  a.logits = m->logits;
+  a.part_val = m->part_val;
+  a.part_idx = m->part_idx;
+  a.dim = c.dim;
+  a.vocab = c.vocab_size;
+  a.gshift = m->gshift;
+  a.eps = c.rms_eps;
+  // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
+  const bool qn = c.is_quant;
+  KH_DISPATCH_U(k_cls, qn, m->u_dim, m->grid_cls, cls_lds_bytes(qn, c.dim), m->stream, a);
+}
+void launch_sample(kh_model* m, int advance, int n_forced) {
+  const kh_config& c = m->cfg;
+  KhSampleArgs a;
+  a.part_val = m->part_val;
+  a.part_idx = m->part_idx;
+  a.nparts = m->nparts;
+  a.forced = n_forced > 0 ? m->d_forced : nullptr;
+  a.n_forced = n_forced;
+  a.words = m->d_words;
+  a.words_cap = m->seq_cap;
+  a.d_next = m->d_next;
+  a.d_token = m->d_token;
+  a.d_pos = m->d_pos;
+  a.tok_emb = m->tok_emb;
+  a.x = m->x;
+  a.dim = c.dim;
+  a.vocab = c.vocab_size;
+  a.advance = advance;
+  hipLaunchKernelGGL(k_sample, dim3(1), dim3(KH_WG), 0, m->stream, a);
+}
+
+// one fused decode step = 5L + 2 launches.  ev (optional) receives an event after each launch.
+void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev) {
+  int e = 0;
+  auto mark = [&]() {
+    if (ev) (void)hipEventRecord(ev[e++], m->stream);
+  };
+  mark();
+  for (int l = 0; l < m->cfg.layer_num; ++l) {
+    launch_qkv(m, l);
+    mark();
+    launch_attn(m, l);
+    mark();
+    launch_wo(m, l);
+    mark();
+    launch_ffn13(m, l);
+    mark();
+    launch_w2(m, l);
+    mark();
+  }
+  launch_cls(m);
+  mark();
+  launch_sample(m, advance, n_forced);
+  mark();
+}
+
+// the reference's own launch sequence, one C-ABI op per reference kernel (llama3.cpp:147-167)
+int launch_step_unfused(kh_model* m, int pos) {
+  const kh_config& c = m->cfg;
+  void* s = (void*)m->stream;
+  int rc;
+#define KH_TRY(x)          \
+  if ((rc = (x)) != KH_OK) \
+  return rc
+  auto lin = [&](const KhLin& L, const float* in, float* out, int M, int K) -> int {
+    int r = c.is_quant ? kh_matmul_q8(in, (const int8_t*)L.w, L.scales, c.group_size, out, M, K, s)
+                       : kh_matmul_f32(in, (const float*)L.w, out, M, K, 1.f, s);
+    if (r == KH_OK && L.bias) r = kh_add_f32(out, L.bias, out, K, s);  // matmul.cpp:74-77
+    return r;
+  };
+  for (int l = 0; l < c.layer_num; ++l) {
+    const LayerW& W = m->layers[l];
+    float* krow = m->kcache + ((size_t)l * c.cache_len + pos) * c.kv_dim;
+    float* vrow = m->vcache + ((size_t)l * c.cache_len + pos) * c.kv_dim;
+    KH_TRY(kh_rmsnorm_f32(m->x, W.att_norm, m->rms, c.dim, c.rms_eps, s));
+    KH_TRY(lin(W.wq, m->rms, m->q, c.dim, c.dim));
+    KH_TRY(lin(W.wk, m->rms, krow, c.dim, c.kv_dim));
+    KH_TRY(lin(W.wv, m->rms, vrow, c.dim, c.kv_dim));
+    KH_TRY(kh_rope_f32(c.dim, c.kv_dim, c.head_size, m->q, krow, nullptr, pos, m->sin_cache,
+                       m->cos_cache, c.rope_mode, s));
+    KH_TRY(kh_mha_f32(nullptr, pos, c.head_num, l, c.cache_len, c.kv_dim, c.kv_mul, c.head_size,
+                      m->att, m->q, m->score, m->kcache, m->vcache, s));
+    KH_TRY(lin(W.wo, m->att, m->q /* kAttnOutput aliases kQuery, llama3.cpp:478-489 */, c.dim,
+               c.dim));
+    KH_TRY(kh_add_f32(m->x, m->q, m->x, c.dim, s));
+    KH_TRY(kh_rmsnorm_f32(m->x, W.ffn_norm, m->rms, c.dim, c.rms_eps, s));
+    KH_TRY(lin(W.w1, m->rms, m->h1, c.dim, c.hidden_dim));
+    KH_TRY(lin(W.w3, m->rms, m->h3, c.dim, c.hidden_dim));
+    KH_TRY(kh_swiglu_f32(m->h1, m->h3, m->h1, c.hidden_dim, s));
+    KH_TRY(lin(W.w2, m->h1, m->w2o, c.hidden_dim, c.dim));
+    KH_TRY(kh_add_f32(m->x, m->w2o, m->x, c.dim, s));
+  }
+  KH_TRY(kh_rmsnorm_f32(m->x, m->final_norm, m->x, c.dim, c.rms_eps, s));
+  KH_TRY(lin(m->cls, m->x, m->logits, c.dim, c.vocab_size));
+  KH_TRY(kh_argmax_f32(m->logits, c.vocab_size, m->d_next, s));
+#undef KH_TRY
+  return KH_OK;
+}
+
+void set_state(kh_model* m, int token, int pos) {
+  hipLaunchKernelGGL(k_set_state, dim3(1), dim3(KH_WG), 0, m->stream, token, pos, m->d_token,
+                     m->d_pos, m->tok_emb, m->x, m->cfg.dim);
+}
+
+template <typename T>
+int dalloc(T** p, size_t n) {
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  return e == hipSuccess ? KH_OK : (int)e;
+}
+
+int ensure_seq_cap(kh_model* m, int n) {
+  if (n <= m->seq_cap) return KH_OK;
+  if (m->d_forced) (void)hipFree(m->d_forced);
+  if (m->d_words) (void)hipFree(m->d_words);
+  m->d_forced = m->d_words = nullptr;
+  m->seq_cap = 0;
+  int rc;
+  if ((rc = dalloc(&m->d_forced, (size_t)n + 1)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->d_words, (size_t)n + 1)) != KH_OK) return rc;
+  m->seq_cap = n;
+  // the graph captured pointers/capacity: rebuild
+  if (m->gexec) {
+    (void)hipGraphExecDestroy(m->gexec);
+    m->gexec = nullptr;
+  }
+  if (m->graph) {
+    (void)hipGraphDestroy(m->graph);
+    m->graph = nullptr;
+  }
+  return KH_OK;
+}
+
+int ensure_graph(kh_model* m, int n_forced) {
+  if (m->gexec) return KH_OK;
+  KH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+  launch_step_fused(m, /*advance=*/1, n_forced, nullptr);
+  hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
+  if (e != hipSuccess) return (int)e;
+  KH_CHECK_HIP(hipGraphInstantiate(&m->gexec, m->graph, nullptr, nullptr, 0));
+  return KH_OK;
+}
+
+// ---- weight table ------------------------------------------------------------------------
+// Byte offsets are relative to the weight data (= file bytes after the header), mirroring
+// kuiperllama_amd/binfmt.py::layout.
+int build_weight_table(kh_model* m) {
+  const kh_config& c = m->cfg;
+  const int L = c.layer_num, dim = c.dim, kvd = c.kv_dim, hid = c.hidden_dim, V = c.vocab_size;
+  m->layers.assign((size_t)L, LayerW{});
+  char* base = m->arena;
+  size_t off = 0;
+  if (!c.is_quant) {
+    const bool bias = c.family == KH_FAMILY_QWEN2;
+    auto takef = [&](size_t n) {
+      const float* p = (const float*)(base + off);
+      off += n * sizeof(float);
+      return p;
+    };
+    m->tok_emb = takef((size_t)V * dim);
+    for (int l = 0; l < L; ++l) m->layers[l].att_norm = takef((size_t)dim);
+    for (int l = 0; l < L; ++l) {
+      m->layers[l].wq.w = takef((size_t)dim * dim);
+      if (bias) m->layers[l].wq.bias = takef((size_t)dim);
+    }
+    for (int l = 0; l < L; ++l) {
+      m->layers[l].wk.w = takef((size_t)kvd * dim);
+      if (bias) m->layers[l].wk.bias = takef((size_t)kvd);
+    }
+    for (int l = 0; l < L; ++l) {
+      m->layers[l].wv.w = takef((size_t)kvd * dim);
+      if (bias) m->layers[l].wv.bias = takef((size_t)kvd);
+    }
+    for (int l = 0; l < L; ++l) m->layers[l].wo.w = takef((size_t)dim * dim);
+    for (int l = 0; l < L; ++l) m->layers[l].ffn_norm = takef((size_t)dim);
+    for (int l = 0; l < L; ++l) m->layers[l].w1.w = takef((size_t)hid * dim);
+    for (int l = 0; l < L; ++l) m->layers[l].w2.w = takef((size_t)dim * hid);
+    for (int l = 0; l < L; ++l) m->layers[l].w3.w = takef((size_t)hid * dim);
+    m->final_norm = takef((size_t)dim);
+    (void)takef((size_t)c.seq_len * c.head_size);  // freqs_cos + freqs_sin: skipped (:367-368)
+    if (c.is_shared_weight) {
+      m->cls.w = m->tok_emb;  // llama3.cpp:372-375
+    } else {
+      m->cls.w = takef((size_t)V * dim);
+    }
+  } else {
+    const size_t gs = (size_t)c.group_size;
+    auto takeq = [&](KhLin& Lw, size_t K, size_t M) {
+      const size_t n = K * M;
+      Lw.w = base + off;
+      Lw.scales = (const float*)(base + off + n);  // layer.cpp:209-215
+      off += n + (n / gs) * sizeof(float);
+    };
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wq, dim, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wk, kvd, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wv, kvd, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wo, dim, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].w1, hid, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].w2, dim, hid);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].w3, hid, dim);
+    takeq(m->cls, V, dim);
+    const float* fp = (const float*)(base + off);
+    m->tok_emb = fp;
+    fp += (size_t)V * dim;
+    for (int l = 0; l < L; ++l) m->layers[l].att_norm = fp + (size_t)l * dim;
+    fp += (size_t)L * dim;
+    for (int l = 0; l < L; ++l) m->layers[l].ffn_norm = fp + (size_t)l * dim;
+    fp += (size_t)L * dim;
+    m->final_norm = fp;
+    fp += dim;
+    off = (size_t)((const char*)fp - base);
+  }
+  if (off > m->arena_bytes) return KH_ERR_FORMAT;
+  return KH_OK;
+}
+
+int parse_header(const int32_t* h, const kh_model_opts* o, kh_config* c) {
+  // model.cpp:57-71, 125-151
+  memset(c, 0, sizeof(*c));
+  c->dim = h[0];
+  c->hidden_dim = h[1];
+  c->layer_num = h[2];
+  c->head_num = h[3];
+  c->kv_head_num = h[4];
+  c->is_shared_weight = h[5] > 0;
+  c->vocab_size = h[5] < 0 ? -h[5] : h[5];
+  c->seq_len = h[6];
+  c->is_quant = o->is_quant ? 1 : 0;
+  c->group_size = o->is_quant ? h[7] : 0;
+  if (c->dim <= 0 || c->hidden_dim <= 0 || c->layer_num <= 0 || c->head_num <= 0 ||
+      c->kv_head_num <= 0 || c->vocab_size <= 0 || c->seq_len <= 0)
+    return KH_ERR_FORMAT;
+  if (c->dim % c->head_num || c->head_num % c->kv_head_num) return KH_ERR_FORMAT;
+  c->kv_dim = (c->dim * c->kv_head_num) / c->head_num;
+  c->kv_mul = c->head_num / c->kv_head_num;
+  c->head_size = c->dim / c->head_num;
+  c->family = o->family;
+  c->rope_mode = o->rope_mode;
+  c->rope_theta = o->rope_theta;
+  c->rms_eps = o->rms_eps;
+  c->cache_len = (o->max_seq_len > 0 && o->max_seq_len < c->seq_len) ? o->max_seq_len : c->seq_len;
+  if (c->is_quant) {
+    if (c->group_size <= 0) return KH_ERR_FORMAT;
+    // the reference wires an int8 classifier onto fp32 embedding bytes when the classifier
+    // is tied (llama3.cpp:259-262) and has no Qwen2 int8 bias layout: refuse both
+    if (c->is_shared_weight || c->family == KH_FAMILY_QWEN2) return KH_ERR_UNSUPPORTED;
+  }
+  if (o->rope_mode != KH_ROPE_HALF && o->rope_mode != KH_ROPE_INTERLEAVED) return KH_ERR_INVALID_ARG;
+  if (o->family != KH_FAMILY_LLAMA && o->family != KH_FAMILY_QWEN2) return KH_ERR_INVALID_ARG;
+  if (!(o->rope_theta > 0.f) || !(o->rms_eps > 0.f)) return KH_ERR_INVALID_ARG;
+  // vector-path preconditions of the fused kernels
+  const int a = c->is_quant ? 16 : 4;
+  if (c->dim % a || c->hidden_dim % a || c->head_size % 4 || (c->head_size & 1) ||
+      c->head_size > 256 || c->kv_dim % 4 || (c->dim & 1) || (c->kv_dim & 1))
+    return KH_ERR_UNSUPPORTED;
+  if (c->is_quant) {
+    const int gs = ilog2_exact(c->group_size);
+    if (gs < 4 || c->dim % c->group_size || c->hidden_dim % c->group_size) return KH_ERR_UNSUPPORTED;
+  }
+  return KH_OK;
+}
+
+size_t expected_weight_bytes(const kh_config& c) {
+  const size_t L = c.layer_num, dim = c.dim, kvd = c.kv_dim, hid = c.hidden_dim, V = c.vocab_size;
+  const size_t lin = L * (2 * dim * dim + 2 * kvd * dim + 3 * hid * dim);
+  if (!c.is_quant) {
+    size_t n = V * dim + 2 * L * dim + lin + dim + (size_t)c.seq_len * c.head_size;
+    if (c.family == KH_FAMILY_QWEN2) n += L * (dim + 2 * kvd);
+    if (!c.is_shared_weight) n += V * dim;
+    return n * sizeof(float);
+  }
+  const size_t q = lin + V * dim;
+  return q + (q / (size_t)c.group_size) * sizeof(float) + (V * dim + 2 * L * dim + dim) * sizeof(float);
+}
+
+int finish_create(kh_model* m) {
+  const kh_config& c = m->cfg;
+  int rc;
+  if ((rc = build_weight_table(m)) != KH_OK) return rc;
+  m->gshift = c.is_quant ? ilog2_exact(c.group_size) : 0;
+  const size_t CL = (size_t)c.cache_len;
+#define KH_ALLOC(ptr, n) \
+  if ((rc = dalloc(&(ptr), (n))) != KH_OK) return rc
+  KH_ALLOC(m->x, (size_t)c.dim);
+  KH_ALLOC(m->rms, (size_t)c.dim);
+  KH_ALLOC(m->q, (size_t)c.dim);
+  KH_ALLOC(m->att, (size_t)c.dim);
+  KH_ALLOC(m->w2o, (size_t)c.dim);
+  KH_ALLOC(m->h1, (size_t)c.hidden_dim);
+  KH_ALLOC(m->h3, (size_t)c.hidden_dim);
+  KH_ALLOC(m->logits, (size_t)c.vocab_size);
+  KH_ALLOC(m->score, (size_t)c.head_num * CL);
+  KH_ALLOC(m->kcache, (size_t)c.layer_num * CL * c.kv_dim);
+  KH_ALLOC(m->vcache, (size_t)c.layer_num * CL * c.kv_dim);
+  KH_ALLOC(m->sin_cache, CL * c.head_size);
+  KH_ALLOC(m->cos_cache, CL * c.head_size);
+  KH_ALLOC(m->d_pos, 1);
+  KH_ALLOC(m->d_token, 1);
+  KH_ALLOC(m->d_next, 1);
+  // launch geometry
+  m->u_dim = pick_u(c.is_quant, c.dim);
+  m->u_hid = pick_u(c.is_quant, c.hidden_dim);
+  m->grid_qkv = grid_for((c.dim + 2 * c.kv_dim) / 2);
+  m->grid_wo = grid_for(c.dim / 2);
+  m->grid_ffn = grid_for(c.hidden_dim);
+  m->grid_w2 = grid_for(c.dim / 2);
+  m->grid_cls = grid_for((c.vocab_size + 1) / 2);
+  m->nparts = m->grid_cls;
+  KH_ALLOC(m->part_val, (size_t)m->nparts);
+  KH_ALLOC(m->part_idx, (size_t)m->nparts);
+#undef KH_ALLOC
+  KH_CHECK_HIP(hipMemsetAsync(m->kcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
+  KH_CHECK_HIP(hipMemsetAsync(m->vcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
+  KH_CHECK_HIP(hipMemsetAsync(m->d_pos, 0, sizeof(int32_t), m->stream));
+  KH_CHECK_HIP(hipMemsetAsync(m->d_token, 0, sizeof(int32_t), m->stream));
+  // sin/cos table: computed on the host with libm exactly as the CPU backend does
+  // (cpu/rope_kernel.cpp:4-16) so the fp32 table is bit-identical to the CPU reference's,
+  // then uploaded once.  (kh_sincos_cache_f32 is the on-device twin of sin_cos_cache_calc_cu.)
+  {
+    const size_t n = CL * c.head_size;
+    std::vector<float> hs_(n), hc_(n);
+    std::vector<float> freq((size_t)c.head_size);
+    for (int d = 0; d < c.head_size; ++d)
+      freq[d] = 1.0f / powf(c.rope_theta, (float)d / (float)c.head_size);
+    for (size_t p = 0; p < CL; ++p)
+      for (int d = 0; d < c.head_size; ++d) {
+        const float val = (float)p * freq[d];
+        hs_[p * c.head_size + d] = sinf(val);
+        hc_[p * c.head_size + d] = cosf(val);
+      }
+    KH_CHECK_HIP(hipMemcpy(m->sin_cache, hs_.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    KH_CHECK_HIP(hipMemcpy(m->cos_cache, hc_.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // big activation vectors (hidden > 16 K floats) need the >64 KiB dynamic-LDS opt-in
+  const size_t lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim);
+  if (lds_need > 160 * 1024) return KH_ERR_UNSUPPORTED;
+  if (lds_need > 64 * 1024) {
+    const int v = (int)lds_need;
+    (void)hipFuncSetAttribute((const void*)k_gemv_res<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+    (void)hipFuncSetAttribute((const void*)k_gemv_res<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+    (void)hipFuncSetAttribute((const void*)k_gemv_res<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+    (void)hipFuncSetAttribute((const void*)k_gemv_res<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+    (void)hipFuncSetAttribute((const void*)k_gemv_res<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+  }
+  KH_CHECK_HIP(hipEventCreate(&m->ev0));
+  KH_CHECK_HIP(hipEventCreate(&m->ev1));
+  if ((rc = ensure_seq_cap(m, 256)) != KH_OK) return rc;
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+
+int new_model(const int32_t* h_header, const kh_model_opts* opts, kh_model** out) {
+  if (!h_header || !opts || !out) return KH_ERR_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return KH_ERR_NO_DEVICE;
+  }
+  if (opts->device < 0 || opts->device >= ndev) return KH_ERR_INVALID_ARG;
+  kh_config cfg;
+  int rc = parse_header(h_header, opts, &cfg);
+  if (rc != KH_OK) return rc;
+  KH_CHECK_HIP(hipSetDevice(opts->device));
+  kh_model* m = new (std::nothrow) kh_model();
+  if (!m) return (int)hipErrorOutOfMemory;
+  m->cfg = cfg;
+  m->opts = *opts;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete m;
+    return (int)e;
+  }
+  *out = m;
+  return KH_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" void kh_model_destroy(kh_model* m) {
+  if (!m) return;
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  if (m->ev0) (void)hipEventDestroy(m->ev0);
+  if (m->ev1) (void)hipEventDestroy(m->ev1);
+  void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
+                  m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
+                  m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
+                  m->d_forced, m->d_words};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (m->owns_arena && m->arena) (void)hipFree(m->arena);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" int kh_model_create_from_device_weights(const int32_t* h_header,
+                                                   const void* d_weight_data,
+                                                   size_t weight_nbytes,
+                                                   const kh_model_opts* opts, kh_model** out) {
+  if (!d_weight_data || !kh_aligned16(d_weight_data)) return KH_ERR_INVALID_ARG;
+  kh_model* m = nullptr;
+  int rc = new_model(h_header, opts, &m);
+  if (rc != KH_OK) return rc;
+  if (weight_nbytes < expected_weight_bytes(m->cfg)) {
+    kh_model_destroy(m);
+    *out = nullptr;
+    return KH_ERR_FORMAT;
+  }
+  m->arena = (char*)const_cast<void*>(d_weight_data);
+  m->owns_arena = false;
+  m->arena_bytes = weight_nbytes;
+  m->cfg.weight_bytes = (int64_t)expected_weight_bytes(m->cfg);
+  rc = finish_create(m);
+  if (rc != KH_OK) {
+    kh_model_destroy(m);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbytes,
+                                               const kh_model_opts* opts, kh_model** out) {
+  if (!h_image || !opts || !out) return KH_ERR_INVALID_ARG;
+  const size_t hdr = opts->is_quant ? 32 : 28;
+  if (nbytes < hdr) return KH_ERR_FORMAT;
+  int32_t header[8] = {0};
+  memcpy(header, h_image, hdr);
+  kh_model* m = nullptr;
+  int rc = new_model(header, opts, &m);
+  if (rc != KH_OK) return rc;
+  const size_t need = expected_weight_bytes(m->cfg);
+  if (nbytes - hdr < need) {
+    kh_model_destroy(m);
+    *out = nullptr;
+    return KH_ERR_FORMAT;
+  }
+  hipError_t e = hipMalloc((void**)&m->arena, need);
+  if (e == hipSuccess) {
+    m->owns_arena = true;
+    m->arena_bytes = need;
+    // weights go up once, in file order, into one arena (the reference cudaMallocs and copies
+    // every tensor separately: tensor.cpp:104-119)
+    e = hipMemcpy(m->arena, (const char*)h_image + hdr, need, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    kh_model_destroy(m);
+    *out = nullptr;
+    return (int)e;
+  }
+  m->cfg.weight_bytes = (int64_t)need;
+  rc = finish_create(m);
+  if (rc != KH_OK) {
+    kh_model_destroy(m);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* opts,
+                                         kh_model** out) {
+  if (!path || !opts || !out) return KH_ERR_INVALID_ARG;
+  // model.cpp:41-123: open + fstat + mmap(PROT_READ, MAP_PRIVATE)
+  const int fd = open(path, O_RDONLY);
+  if (fd == -1) return KH_ERR_IO;
+  struct stat st;
+  if (fstat(fd, &st) == -1 || st.st_size <= 0) {
+    close(fd);
+    return KH_ERR_IO;
+  }
+  void* data = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (data == MAP_FAILED || data == nullptr) {
+    close(fd);
+    return KH_ERR_IO;
+  }
+  const int rc = kh_model_create_from_host_image(data, (size_t)st.st_size, opts, out);
+  munmap(data, (size_t)st.st_size);
+  close(fd);
+  return rc;
+}
+
+extern "C" int kh_model_get_config(const kh_model* m, kh_config* out) {
+  if (!m || !out) return KH_ERR_INVALID_ARG;
+  *out = m->cfg;
+  return KH_OK;
+}
+extern "C" void* kh_model_stream(kh_model* m) { return m ? (void*)m->stream : nullptr; }
+
+extern "C" int kh_model_get_logits(kh_model* m, float* h_logits) {
+  if (!m || !h_logits) return KH_ERR_INVALID_ARG;
+  KH_CHECK_HIP(hipMemcpyAsync(h_logits, m->logits, sizeof(float) * m->cfg.vocab_size,
+                              hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+extern "C" int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache) {
+  if (!m || !d_kcache || !d_vcache) return KH_ERR_INVALID_ARG;
+  *d_kcache = m->kcache;
+  *d_vcache = m->vcache;
+  return KH_OK;
+}
+
+extern "C" int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows,
+                                float* h_k, float* h_v) {
+  if (!m || !h_k || !h_v || layer < 0 || layer >= m->cfg.layer_num || row0 < 0 || nrows <= 0 ||
+      row0 + nrows > m->cfg.cache_len)
+    return KH_ERR_INVALID_ARG;
+  const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
+  const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
+  KH_CHECK_HIP(hipMemcpyAsync(h_k, m->kcache + off, nb, hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipMemcpyAsync(h_v, m->vcache + off, nb, hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+
+extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t is_prompt,
+                                int32_t exec, int32_t* h_next) {
+  if (!m || !h_next) return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if (token < 0 || token >= c.vocab_size || pos < 0 || pos >= c.cache_len) return KH_ERR_RANGE;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  set_state(m, token, pos);  // embedding() + fill_input (llama3.cpp:578-598, model.cpp:245-263)
+  int rc = KH_OK;
+  if (exec == KH_EXEC_UNFUSED) {
+    rc = launch_step_unfused(m, pos);
+  } else if (exec == KH_EXEC_FUSED || exec == KH_EXEC_GRAPH) {
+    launch_step_fused(m, /*advance=*/0, /*n_forced=*/0, nullptr);
+    rc = kh_launch_status();
+  } else {
+    return KH_ERR_INVALID_ARG;
+  }
+  if (rc != KH_OK) return rc;
+  int32_t next = -1;
+  KH_CHECK_HIP(hipMemcpyAsync(&next, m->d_next, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  *h_next = is_prompt ? -1 : next;  // post_processing (llama3.cpp:733-745)
+  return KH_OK;
+}
+
+extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
+                                 int32_t total_steps, int32_t exec, int32_t* h_words,
+                                 int32_t* n_words, float* h_elapsed_ms) {
+  if (!m || !h_prompt || n_prompt <= 0 || total_steps <= 0 || !h_words || !n_words)
+    return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if (total_steps > c.cache_len) return KH_ERR_RANGE;
+  for (int i = 0; i < n_prompt; ++i)
+    if (h_prompt[i] < 0 || h_prompt[i] >= c.vocab_size) return KH_ERR_RANGE;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  int rc;
+  *n_words = 0;
+
+  if (exec == KH_EXEC_UNFUSED) {
+    // the reference loop verbatim: host drives every step and reads `next` back each time
+    KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+    int pos = 0, next = -1, nw = 0;
+    while (pos < total_steps) {
+      const bool is_prompt = pos < n_prompt - 1;
+      const int tok = pos <= n_prompt - 1 ? h_prompt[pos] : next;
+      int got = -1;
+      if ((rc = kh_model_predict(m, tok, pos, is_prompt, KH_EXEC_UNFUSED, &got)) != KH_OK) return rc;
+      next = is_prompt ? h_prompt[pos + 1] : got;
+      h_words[nw++] = next;
+      pos += 1;
+    }
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+    KH_CHECK_HIP(hipEventSynchronize(m->ev1));
+    if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
+    *n_words = nw;
+    return KH_OK;
+  }
+  if (exec != KH_EXEC_GRAPH && exec != KH_EXEC_FUSED) return KH_ERR_INVALID_ARG;
+
+  if ((rc = ensure_seq_cap(m, total_steps)) != KH_OK) return rc;
+  // forced[i] = token fed at position i while inside the prompt, -1 afterwards
+  std::vector<int32_t> forced((size_t)m->seq_cap + 1, -1);
+  for (int i = 0; i < n_prompt && i <= m->seq_cap; ++i) forced[i] = h_prompt[i];
+  KH_CHECK_HIP(hipMemcpyAsync(m->d_forced, forced.data(), forced.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));  // `forced` is a stack-lifetime staging buffer
+  const int n_forced = m->seq_cap + 1;
+  if (exec == KH_EXEC_GRAPH && (rc = ensure_graph(m, n_forced)) != KH_OK) return rc;
+
+  set_state(m, h_prompt[0], 0);
+  KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+  for (int s = 0; s < total_steps; ++s) {
+    if (exec == KH_EXEC_GRAPH) {
+      KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
+    } else {
+      launch_step_fused(m, 1, n_forced, nullptr);
+    }
+  }
+  KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+  if ((rc = kh_launch_status()) != KH_OK) return rc;
+  KH_CHECK_HIP(hipMemcpyAsync(h_words, m->d_words, sizeof(int32_t) * total_steps,
+                              hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
+  *n_words = total_steps;
+  return KH_OK;
+}
+
+static const char* const kKClassNames[KH_NUM_KCLASS] = {"qkv", "attn", "wo", "ffn13", "w2", "cls",
+                                                       "sample"};
+extern "C" const char* kh_kclass_name(int k) {
+  return (k >= 0 && k < KH_NUM_KCLASS) ? kKClassNames[k] : "?";
+}
+
+extern "C" int kh_model_profile_step(kh_model* m, int32_t start_pos, int32_t n_steps,
+                                     float* h_avg_us, int32_t* h_count) {
+  if (!m || !h_avg_us || !h_count || n_steps <= 0 || start_pos < 0) return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if (start_pos + n_steps > c.cache_len) return KH_ERR_RANGE;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  const int L = c.layer_num;
+  const int nk = 5 * L + 2;
+  std::vector<hipEvent_t> ev((size_t)nk + 1);
+  for (auto& e : ev) KH_CHECK_HIP(hipEventCreate(&e));
+  double acc[KH_NUM_KCLASS] = {0};
+  int cnt[KH_NUM_KCLASS] = {0};
+  set_state(m, 1 % c.vocab_size, start_pos);
+  int rc = KH_OK;
+  for (int s = 0; s < n_steps && rc == KH_OK; ++s) {
+    launch_step_fused(m, 1, 0, ev.data());
+    hipError_t e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) {
+      rc = (int)e;
+      break;
+    }
+    for (int k = 0; k < nk; ++k) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+      int cls;
+      if (k < 5 * L)
+        cls = k % 5;  // qkv, attn, wo, ffn13, w2
+      else
+        cls = k == 5 * L ? KH_K_CLS : KH_K_SAMPLE;
+      acc[cls] += (double)ms * 1000.0;
+      cnt[cls] += 1;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  for (int k = 0; k < KH_NUM_KCLASS; ++k) {
+    h_avg_us[k] = cnt[k] ? (float)(acc[k] / cnt[k]) : 0.f;
+    h_count[k] = cnt[k] / n_steps;
+  }
+  return rc;
+}

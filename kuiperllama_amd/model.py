@@ -1,0 +1,143 @@
+"""Model-level Python mirror of model::LLama2Model / Qwen2Model for the decode path
+(kuiper/include/model/model.h:20-56, kuiper/source/model/llama3.cpp:107-167, 642-650,
+733-745; demo/main.cpp:5-47) over libkuiper_hip.so.  All compute is in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _ffi, binfmt
+from ._ffi import KH_EXEC_FUSED, KH_EXEC_GRAPH, KH_EXEC_UNFUSED  # noqa: F401
+
+EXEC = {"graph": KH_EXEC_GRAPH, "fused": KH_EXEC_FUSED, "unfused": KH_EXEC_UNFUSED}
+
+
+def _opts(spec: binfmt.ModelSpec, max_seq_len: int, device: int) -> _ffi.ModelOpts:
+    return _ffi.ModelOpts(spec.family, int(spec.quant), spec.rope_mode, spec.rope_theta,
+                          spec.rms_eps, max_seq_len, device, 0)
+
+
+class KuiperModel:
+    """Owns a kh_model handle.  Construct with one of the from_* classmethods."""
+
+    def __init__(self, handle: int, spec: binfmt.ModelSpec, keepalive=None):
+        self._h = C.c_void_p(handle)
+        self.spec = spec
+        self._keep = keepalive
+        cfg = _ffi.Config()
+        _ffi.check(_ffi.lib().kh_model_get_config(self._h, C.byref(cfg)), "kh_model_get_config")
+        self.cfg = cfg
+
+    # ---- construction ------------------------------------------------------------------
+    @classmethod
+    def from_file(cls, path: str, spec: binfmt.ModelSpec, max_seq_len: int = 0,
+                  device: int = 0) -> "KuiperModel":
+        h = C.c_void_p()
+        o = _opts(spec, max_seq_len, device)
+        _ffi.check(_ffi.lib().kh_model_create_from_file(path.encode(), C.byref(o), C.byref(h)),
+                   "kh_model_create_from_file")
+        return cls(h.value, spec)
+
+    @classmethod
+    def from_host_image(cls, image: np.ndarray, spec: binfmt.ModelSpec, max_seq_len: int = 0,
+                        device: int = 0) -> "KuiperModel":
+        assert image.dtype == np.uint8 and image.flags["C_CONTIGUOUS"]
+        h = C.c_void_p()
+        o = _opts(spec, max_seq_len, device)
+        _ffi.check(_ffi.lib().kh_model_create_from_host_image(image.ctypes.data, image.size,
+                                                              C.byref(o), C.byref(h)),
+                   "kh_model_create_from_host_image")
+        return cls(h.value, spec)
+
+    @classmethod
+    def from_device_image(cls, image: torch.Tensor, spec: binfmt.ModelSpec, max_seq_len: int = 0,
+                          device: int = 0) -> "KuiperModel":
+        """image: uint8 GPU tensor with the .bin bytes (header included).  The weights are
+        re-based once so that the data after the header is 256-byte aligned, then used in
+        place (not copied again, not owned by the library)."""
+        assert image.is_cuda and image.dtype == torch.uint8
+        hb = spec.header_bytes()
+        header = np.frombuffer(image[:32].cpu().numpy().tobytes(), dtype=np.int32).copy()
+        if (image.data_ptr() + hb) % 16 == 0:
+            weights = image[hb:]
+            keep = image
+        else:
+            weights = torch.empty(image.numel() - hb, dtype=torch.uint8, device=image.device)
+            weights.copy_(image[hb:])
+            keep = weights
+        torch.cuda.synchronize()
+        h = C.c_void_p()
+        o = _opts(spec, max_seq_len, device)
+        hdr = (C.c_int32 * 8)(*header.tolist()[:8])
+        _ffi.check(_ffi.lib().kh_model_create_from_device_weights(hdr, weights.data_ptr(),
+                                                                  weights.numel(), C.byref(o),
+                                                                  C.byref(h)),
+                   "kh_model_create_from_device_weights")
+        return cls(h.value, spec, keepalive=keep)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _ffi.lib().kh_model_destroy(self._h)
+            self._h = C.c_void_p()
+        self._keep = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Model::predict / forward ----------------------------------------------------------
+    def predict(self, token: int, pos: int, is_prompt: bool = False, exec: str = "fused") -> int:
+        nxt = C.c_int32(-1)
+        _ffi.check(_ffi.lib().kh_model_predict(self._h, token, pos, int(is_prompt), EXEC[exec],
+                                               C.byref(nxt)), "kh_model_predict")
+        return int(nxt.value)
+
+    def logits(self) -> np.ndarray:
+        out = np.empty(self.cfg.vocab_size, np.float32)
+        _ffi.check(_ffi.lib().kh_model_get_logits(self._h, out.ctypes.data), "kh_model_get_logits")
+        return out
+
+    def kv_cache_ptrs(self) -> Tuple[int, int]:
+        k, v = C.c_void_p(), C.c_void_p()
+        _ffi.check(_ffi.lib().kh_model_get_kv(self._h, C.byref(k), C.byref(v)), "kh_model_get_kv")
+        return k.value, v.value
+
+    def read_kv(self, layer: int, row0: int, nrows: int):
+        k = np.empty((nrows, self.cfg.kv_dim), np.float32)
+        v = np.empty((nrows, self.cfg.kv_dim), np.float32)
+        _ffi.check(_ffi.lib().kh_model_read_kv(self._h, layer, row0, nrows, k.ctypes.data,
+                                               v.ctypes.data), "kh_model_read_kv")
+        return k, v
+
+    # ---- demo/main.cpp generate() ---------------------------------------------------------
+    def generate(self, prompt: Sequence[int], total_steps: int, exec: str = "graph"
+                 ) -> Tuple[List[int], float]:
+        """Returns (words, elapsed_ms of the step loop measured with HIP events)."""
+        pr = (C.c_int32 * len(prompt))(*[int(t) for t in prompt])
+        words = (C.c_int32 * total_steps)()
+        n = C.c_int32(0)
+        ms = C.c_float(0.0)
+        _ffi.check(_ffi.lib().kh_model_generate(self._h, pr, len(prompt), total_steps, EXEC[exec],
+                                                words, C.byref(n), C.byref(ms)),
+                   "kh_model_generate")
+        return list(words[: n.value]), float(ms.value)
+
+    def profile_step(self, start_pos: int, n_steps: int):
+        """Per-kernel-class average launch duration (us) of the fused step, HIP events."""
+        avg = (C.c_float * _ffi.KH_NUM_KCLASS)()
+        cnt = (C.c_int32 * _ffi.KH_NUM_KCLASS)()
+        _ffi.check(_ffi.lib().kh_model_profile_step(self._h, start_pos, n_steps, avg, cnt),
+                   "kh_model_profile_step")
+        names = [_ffi.lib().kh_kclass_name(i).decode() for i in range(_ffi.KH_NUM_KCLASS)]
+        return {n: {"avg_us": float(avg[i]), "launches_per_step": int(cnt[i])}
+                for i, n in enumerate(names)}
+
+    @property
+    def stream(self) -> int:
+        return int(_ffi.lib().kh_model_stream(self._h) or 0)

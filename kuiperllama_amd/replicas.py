@@ -1,0 +1,62 @@
+"""Multi-GPU = independent replicas: batch-1 greedy decode is single-stream and
+autoregressive, the reference has no sharding and pins device 0 (llama3.cpp:118), so N GPUs run
+N copies of the path with NO data-path collective.  The only communication is the timing
+protocol of the benchmark: barrier, then max-over-ranks of the per-rank wall time.
+
+Kept separate from bench.py so the N>1 logic is covered by world_size-2 gloo tests on CPU.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Tuple
+
+import torch
+
+
+def init_from_env(backend: str, device: torch.device | None = None) -> Tuple[int, int, int]:
+    """-> (rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if not dist.is_initialized():
+            kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def timed_replica_run(run: Callable[[], float | None], steps: int, world: int,
+                      device: torch.device, sync: Callable[[], None]) -> Tuple[float, float]:
+    """Time `run()` (one replica's K steps) bracketed by barrier + device sync on both sides;
+    returns (max wall seconds over ranks, aggregate steps/s = world*steps / max wall)."""
+    import time
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore[no-redef]
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run()
+    sync()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    wall = t1 - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, world * steps / wall
+
+
+def shutdown(world: int) -> None:
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()

@@ -1,0 +1,215 @@
+"""Model-level parity on the GPU through the C-ABI (kh_model_*):
+
+* the committed golden fixtures (reference exporter bytes + reference Python logits),
+* token-for-token greedy parity with the CPU oracle over 128 steps (fp32: the north-star
+  criterion; int8: stated tolerance on logits + token parity on the seeded model),
+* the three execution modes (hipGraph replay / fused eager / unfused reference sequence) agree,
+* KV-cache contents, loader entry points (file, host image, device weights), error paths.
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_MODELS, load_golden
+from kuiperllama_amd import binfmt
+
+pytestmark = pytest.mark.gpu
+
+# fp32 logits tolerance vs the oracle/reference: logits are O(1); summation order differs
+# (wave-strided + butterfly vs 16-way blocked), so a few 1e-6.
+LOGIT_ATOL_F32 = 2e-5
+# int8: the kernel factors the group scale out of the 16-weight runs
+LOGIT_ATOL_Q8 = 5e-5
+
+
+def _atol(spec):
+    return LOGIT_ATOL_Q8 if spec.quant else LOGIT_ATOL_F32
+
+
+@pytest.mark.parametrize("exec_mode", ["fused", "unfused"])
+@pytest.mark.parametrize("name", GOLDEN_MODELS)
+def test_golden_logits(gpu, name, exec_mode):
+    """Logits after each of the 12 golden tokens vs the REFERENCE's Python model."""
+    from kuiperllama_amd.model import KuiperModel
+    spec, img, toks, ref = load_golden(name)
+    m = KuiperModel.from_host_image(img, spec)
+    for t, tok in enumerate(toks):
+        nxt = m.predict(int(tok), t, is_prompt=False, exec=exec_mode)
+        lg = m.logits()
+        err = np.abs(lg - ref[t]).max()
+        assert err <= _atol(spec), f"{name} pos {t}: max logit err {err:.3e}"
+        assert nxt == int(np.argmax(ref[t]))
+    # is_prompt: forward runs, sampling is skipped (llama3.cpp:733-745)
+    assert m.predict(int(toks[0]), 0, is_prompt=True, exec=exec_mode) == -1
+    m.close()
+
+
+@pytest.mark.parametrize("name", GOLDEN_MODELS)
+def test_generate_modes_agree_with_oracle(gpu, oracle, name):
+    from kuiperllama_amd.model import KuiperModel
+    spec, img, toks, _ = load_golden(name)
+    steps = spec.seq_len
+    prompt = [int(t) for t in toks[:3]]
+    want = oracle.OracleModel.from_spec(img, spec).generate(prompt, steps)
+    m = KuiperModel.from_host_image(img, spec)
+    for mode in ("graph", "fused", "unfused", "graph"):
+        words, ms = m.generate(prompt, steps, exec=mode)
+        assert words == want, f"{name} mode {mode}: first diff at " \
+            f"{next(i for i, (a, b) in enumerate(zip(words, want)) if a != b)}"
+        assert ms > 0
+    m.close()
+
+
+def test_kv_cache_matches_oracle(gpu, oracle):
+    from kuiperllama_amd.model import KuiperModel
+    spec, img, toks, _ = load_golden("hf_llama_half")
+    om = oracle.OracleModel.from_spec(img, spec)
+    m = KuiperModel.from_host_image(img, spec)
+    for t, tok in enumerate(toks):
+        om.forward(int(tok), t)
+        m.predict(int(tok), t, exec="fused")
+    ko, vo = om.kv_cache()
+    T = len(toks)
+    for l in range(spec.n_layers):
+        kg, vg = m.read_kv(l, 0, T)
+        # rotated keys / raw values in the cache rows (model.cpp:226-243 views)
+        np.testing.assert_allclose(kg, ko[l, :T], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(vg, vo[l, :T], rtol=0, atol=5e-6)
+    m.close()
+
+
+def _synth(spec, seed, gpu):
+    img_d = binfmt.synth_image(spec, seed=seed, device=gpu)
+    torch.cuda.synchronize()
+    return img_d, img_d.cpu().numpy()
+
+
+MID_SPECS = [
+    # mid-size stand-ins with the BASELINE geometries' ratios (GQA 4:1 half-rope, MHA hs=128
+    # interleaved int8, Qwen kv_mul=7 + bias) that the oracle finishes in seconds
+    binfmt.ModelSpec(512, 1408, 4, 8, 2, 4096, 160, True, binfmt.FAMILY_LLAMA, False, 64,
+                     binfmt.ROPE_HALF, 500000.0, 1e-5, "mid-llama3"),
+    binfmt.ModelSpec(512, 1408, 3, 4, 4, 2048, 160, False, binfmt.FAMILY_LLAMA, True, 64,
+                     binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "mid-llama2-int8"),
+    binfmt.ModelSpec(448, 1216, 3, 7, 1, 3000, 160, True, binfmt.FAMILY_QWEN2, False, 64,
+                     binfmt.ROPE_HALF, 1000000.0, 1e-6, "mid-qwen2"),
+    binfmt.PRESETS["stories15M"],
+]
+
+
+@pytest.mark.parametrize("spec", MID_SPECS, ids=lambda s: s.name)
+def test_token_parity_128_steps(gpu, oracle, spec):
+    """North-star criterion: greedy token ids identical to the CPU path over 128 steps
+    (demo/main.cpp generate(…, 128)), prompt [1, 263] (= BOS + "a" of the demo)."""
+    from kuiperllama_amd.model import KuiperModel
+    img_d, img_h = _synth(spec, 1234, gpu)
+    steps = min(128, spec.seq_len)
+    prompt = [1, 263]
+    om = oracle.OracleModel.from_spec(img_h, spec)
+    want = om.generate(prompt, steps)
+    m = KuiperModel.from_device_image(img_d, spec)
+    words, _ = m.generate(prompt, steps, exec="graph")
+    if words != want:
+        i = next(i for i, (a, b) in enumerate(zip(words, want)) if a != b)
+        # report the top-2 logit margin at the first divergence (SURVEY.md §7 hard part (i))
+        om2 = oracle.OracleModel.from_spec(img_h, spec)
+        seq = prompt + want
+        for p in range(i + 1):
+            lg = om2.forward(seq[p] if p < len(prompt) else want[p - 1], p, oracle.ACC_F64)
+        top2 = np.sort(lg)[-2:]
+        pytest.fail(f"{spec.name}: first divergence at step {i}; fp64-gold top-2 margin "
+                    f"{top2[1] - top2[0]:.3e}")
+    # logits at the last position within tolerance of the oracle's
+    np.testing.assert_allclose(m.logits(), om.logits(), rtol=0, atol=_atol(spec) * 2)
+    m.close()
+
+
+def test_loader_entry_points_agree(gpu):
+    from kuiperllama_amd.model import KuiperModel
+    spec, img, toks, ref = load_golden("ref_llama_mha_untied")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.bin")
+        img.tofile(path)
+        a = KuiperModel.from_file(path, spec)
+    b = KuiperModel.from_host_image(img, spec)
+    c = KuiperModel.from_device_image(torch.from_numpy(img).to(gpu), spec)
+    outs = []
+    for m in (a, b, c):
+        for t, tok in enumerate(toks[:4]):
+            m.predict(int(tok), t)
+        outs.append(m.logits())
+        assert m.cfg.dim == spec.dim and m.cfg.kv_dim == spec.kv_dim
+        assert m.cfg.is_shared_weight == 0 and m.cfg.vocab_size == spec.vocab_size
+        m.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    np.testing.assert_allclose(outs[0], ref[3], rtol=0, atol=LOGIT_ATOL_F32)
+
+
+def test_max_seq_len_caps_cache(gpu):
+    from kuiperllama_amd.model import KuiperModel
+    from kuiperllama_amd import _ffi
+    spec, img, toks, ref = load_golden("hf_llama_half")
+    m = KuiperModel.from_host_image(img, spec, max_seq_len=16)
+    assert m.cfg.cache_len == 16 and m.cfg.seq_len == spec.seq_len
+    for t, tok in enumerate(toks):
+        m.predict(int(tok), t)
+    np.testing.assert_allclose(m.logits(), ref[len(toks) - 1], rtol=0, atol=LOGIT_ATOL_F32)
+    with pytest.raises(_ffi.KhError) as ei:
+        m.predict(1, 16)  # beyond the allocated cache
+    assert ei.value.code == -6
+    with pytest.raises(_ffi.KhError):
+        m.predict(spec.vocab_size, 0)
+    with pytest.raises(_ffi.KhError):
+        m.generate([1], 17)
+    m.close()
+
+
+def test_error_paths(gpu):
+    from kuiperllama_amd.model import KuiperModel
+    from kuiperllama_amd import _ffi
+    spec, img, _, _ = load_golden("ref_llama_gqa_tied")
+    with pytest.raises(_ffi.KhError) as ei:
+        KuiperModel.from_host_image(img[: img.size // 2].copy(), spec)  # truncated file
+    assert ei.value.code == -4
+    # int8 + tied classifier: the reference itself is broken there (llama3.cpp:259-262)
+    bad = binfmt.ModelSpec(**{**binfmt.spec_to_dict(spec), "quant": True})
+    with pytest.raises(_ffi.KhError) as ei:
+        KuiperModel.from_host_image(img, bad)
+    assert ei.value.code in (-2, -4)
+
+
+def test_profile_step_reports_all_kernel_classes(gpu):
+    from kuiperllama_amd.model import KuiperModel
+    spec, img, toks, _ = load_golden("hf_llama_half")
+    m = KuiperModel.from_host_image(img, spec)
+    m.generate([int(t) for t in toks[:2]], 8)
+    prof = m.profile_step(8, 4)
+    assert set(prof) == {"qkv", "attn", "wo", "ffn13", "w2", "cls", "sample"}
+    for k in ("qkv", "attn", "wo", "ffn13", "w2"):
+        assert prof[k]["launches_per_step"] == spec.n_layers and prof[k]["avg_us"] > 0
+    assert prof["cls"]["launches_per_step"] == 1
+    m.close()
+
+
+@pytest.mark.parametrize("preset,steps", [("llama3.2-1b", 24), ("qwen2.5-0.5b", 24)])
+def test_full_size_baseline_shapes(gpu, oracle, preset, steps):
+    """BASELINE.json configs at full size: token parity with the CPU oracle on a bounded number
+    of steps, plus a size-independent property — graph replay == eager fused == unfused
+    reference sequence over 128 steps (idempotent re-generation from the same state)."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.PRESETS[preset]
+    img_d, img_h = _synth(spec, 1234, gpu)
+    m = KuiperModel.from_device_image(img_d, spec, max_seq_len=256)
+    prompt = [1, 263]
+    g, _ = m.generate(prompt, 128, exec="graph")
+    f, _ = m.generate(prompt, 128, exec="fused")
+    assert g == f
+    u, _ = m.generate(prompt, 32, exec="unfused")
+    assert u == g[:32]
+    om = oracle.OracleModel.from_spec(img_h, spec, cache_len=256)
+    want = om.generate(prompt, steps)
+    assert g[:steps] == want
+    m.close()

@@ -1,0 +1,310 @@
+"""Parity of every operator-level HIP kernel (C-ABI, include/kuiper_hip.h) against the CPU
+oracle on the same seeded inputs, plus the reference tests' own known-answer vectors and the
+edge cases they cover.  Tolerances follow the reference's tests (1e-5 rmsnorm/swiglu,
+test/test_op/test_cu_rmsnorm.cpp, test_cu_swiglu.cpp; 1e-3 RoPE in test_cu_rope.cpp) or tighter.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, gpu, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(gpu)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------- matmul fp32
+def test_matmul_reference_known_answers(gpu, oracle):
+    from kuiperllama_amd import ops
+    z = np.load(os.path.join(GOLDEN, "ref_test_vectors.npz"))
+    # test_cu_matmul.cpp:78-106  (3x3: exercises the unaligned generic path)
+    y = torch.zeros(3, device=gpu)
+    ops.matmul(dev(z["matmul_x"], gpu), dev(z["matmul_w"], gpu), y)
+    assert np.array_equal(host(y), z["matmul_y"])
+    # test_load.cpp:49-108 on tmp/test.bin weights
+    w = z["test_bin"][28:].view(np.float32)[: 16 * 128].reshape(16, 128)
+    y = torch.zeros(16, device=gpu)
+    ops.matmul(torch.ones(128, device=gpu), dev(w, gpu), y)
+    assert np.array_equal(host(y)[z["test_bin_matmul_idx"]], z["test_bin_matmul_out"])
+    # test_cu_matmul.cpp:10-46: 4-vector x 4x4 arange, CPU == device exactly
+    x = np.arange(4, dtype=np.float32)
+    w = np.arange(16, dtype=np.float32).reshape(4, 4)
+    y = torch.zeros(4, device=gpu)
+    ops.matmul(dev(x, gpu), dev(w, gpu), y)
+    assert np.array_equal(host(y), oracle.matmul(x, w))
+
+
+@pytest.mark.parametrize("K,M", [(2048, 2048), (512, 2048), (2048, 8192), (4096, 11008),
+                                 (1001, 896), (33, 288), (7, 36), (5, 13), (1, 4), (300, 20000)])
+def test_matmul_f32_vs_oracle(gpu, oracle, K, M):
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(K * 7 + M)
+    x = rng.standard_normal(M).astype(np.float32)
+    w = (0.02 * rng.standard_normal((K, M))).astype(np.float32)
+    y = torch.full((K,), float("nan"), device=gpu)
+    ops.matmul(dev(x, gpu), dev(w, gpu), y, 1.0)
+    got = host(y)
+    gold = oracle.matmul(x, w, acc=oracle.ACC_F64)
+    ref32 = oracle.matmul(x, w, acc=oracle.ACC_F32)
+    bound = 2e-6 * np.linalg.norm(x) * np.linalg.norm(w, axis=1) + 1e-7
+    assert np.all(np.abs(got - gold) <= bound), np.abs(got - gold).max()
+    # the HIP result is as close to exact as the CPU fp32 restatement is (within 4x)
+    assert np.abs(got - gold).max() <= 4 * max(np.abs(ref32 - gold).max(), 1e-7)
+    # scale is honoured (cpu/matmul_kernel.cpp:40)
+    ops.matmul(dev(x, gpu), dev(w, gpu), y, 0.125)
+    np.testing.assert_allclose(host(y), got * 0.125, rtol=1e-6, atol=1e-9)
+
+
+# ---------------------------------------------------------------- matmul int8
+@pytest.mark.parametrize("K,M,group", [(4096, 4096, 64), (512, 11008, 64), (1000, 4096, 64),
+                                       (64, 128, 64), (3, 64, 64), (130, 256, 128), (50, 96, 32),
+                                       (40, 192, 16), (9, 40, 8), (6, 24, 12)])
+def test_matmul_q8_vs_oracle(gpu, oracle, K, M, group):
+    """Stated int8 tolerance: each output within 1e-5 * ||x|| * ||w_row|| of the
+    fp64 gold of the same dequant formula (the kernel factors the group scale out)."""
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(K + 13 * M + group)
+    x = rng.standard_normal(M).astype(np.float32)
+    w = (0.02 * rng.standard_normal(K * M)).astype(np.float32)
+    q, s = oracle.quantize_q80(w, group)
+    q = q.reshape(K, M)
+    y = torch.full((K,), float("nan"), device=gpu)
+    ops.matmul_q8(dev(x, gpu), dev(q, gpu), dev(s, gpu), group, y)
+    got = host(y)
+    gold = oracle.matmul_q8(x, q, s, group, acc=oracle.ACC_F64)
+    deq = q.astype(np.float32).reshape(-1, group) * s[:, None]
+    bound = 1e-5 * np.linalg.norm(x) * np.linalg.norm(deq.reshape(K, M), axis=1) + 1e-7
+    assert np.all(np.abs(got - gold) <= bound), (np.abs(got - gold).max(), bound.min())
+
+
+# ---------------------------------------------------------------- rmsnorm / swiglu / add
+@pytest.mark.parametrize("n", [32, 480, 72480, 2048, 4096, 896, 7, 1])
+def test_rmsnorm_vs_oracle(gpu, oracle, n):
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(n)
+    x = rng.random(n, dtype=np.float32)  # uniform(0,1) like test_cu_rmsnorm.cpp
+    w = rng.random(n, dtype=np.float32)
+    for eps in (1e-5, 1e-6):
+        out = torch.empty(n, device=gpu)
+        ops.rmsnorm(dev(x, gpu), dev(w, gpu), out, eps)
+        np.testing.assert_allclose(host(out), oracle.rmsnorm(x, w, eps), rtol=0, atol=1e-5)
+    # in place (final norm: llama3.cpp:726)
+    xi = dev(x, gpu)
+    ops.rmsnorm(xi, dev(w, gpu), xi, 1e-5)
+    np.testing.assert_allclose(host(xi), oracle.rmsnorm(x, w, 1e-5), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [4832, 8192, 11008, 5, 1])
+def test_swiglu_vs_oracle(gpu, oracle, n):
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(n)
+    a = (3 * rng.standard_normal(n)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    out = torch.empty(n, device=gpu)
+    ops.swiglu(dev(a, gpu), dev(b, gpu), out)
+    np.testing.assert_allclose(host(out), oracle.swiglu(a, b), rtol=1e-6, atol=1e-5)
+    ai = dev(a, gpu)  # out aliases input1 (llama3.cpp:708)
+    ops.swiglu(ai, dev(b, gpu), ai)
+    np.testing.assert_allclose(host(ai), oracle.swiglu(a, b), rtol=1e-6, atol=1e-5)
+
+
+def test_add_reference_cases(gpu, oracle):
+    from kuiperllama_amd import ops
+    # test_cu_add.cpp:7-75
+    out = torch.empty(4832, device=gpu)
+    ops.add(torch.full((4832,), 2.0, device=gpu), torch.full((4832,), 3.0, device=gpu), out)
+    assert np.array_equal(host(out), np.full(4832, 5.0, np.float32))
+    out = torch.empty(62816, device=gpu)
+    ops.add(torch.full((62816,), 2.1, device=gpu), torch.full((62816,), 3.3, device=gpu), out)
+    np.testing.assert_allclose(host(out), 5.4, rtol=1e-6)
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 2048, 4099):
+        a = rng.standard_normal(n).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        out = torch.empty(n, device=gpu)
+        ops.add(dev(a, gpu), dev(b, gpu), out)
+        assert np.array_equal(host(out), oracle.add(a, b))  # single fp32 add: bit-exact
+        # unaligned views (offset by one float) take the scalar path
+        big_a, big_b, big_o = (torch.zeros(n + 1, device=gpu) for _ in range(3))
+        big_a[1:] = dev(a, gpu)
+        big_b[1:] = dev(b, gpu)
+        ops.add(big_a[1:], big_b[1:], big_o[1:])
+        assert np.array_equal(host(big_o)[1:], oracle.add(a, b))
+
+
+# ---------------------------------------------------------------- embedding / argmax
+def test_embedding_reference_case(gpu, oracle):
+    from kuiperllama_amd import ops
+    # test_cu_emb.cpp:6-89
+    w = np.arange(4 * 512, dtype=np.float32).reshape(4, 512)
+    toks = np.array([1, 2], np.int32)
+    out = torch.zeros(2, 512, device=gpu)
+    ops.embedding(dev(toks, gpu), dev(w, gpu), out)
+    assert np.array_equal(host(out), oracle.embedding(toks, w))
+    # > 512 tokens (the reference's fixed 512-block launch truncates, emb_kernel.cu:35,42)
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((97, 36)).astype(np.float32)
+    toks = rng.integers(0, 97, 700).astype(np.int32)
+    out = torch.zeros(700, 36, device=gpu)
+    ops.embedding(dev(toks, gpu), dev(w, gpu), out)
+    assert np.array_equal(host(out), w[toks])
+    # out-of-range token rows are left untouched
+    out = torch.full((2, 36), 7.0, device=gpu)
+    ops.embedding(dev(np.array([97, 3], np.int32), gpu), dev(w, gpu), out)
+    h = host(out)
+    assert np.all(h[0] == 7.0) and np.array_equal(h[1], w[3])
+
+
+@pytest.mark.parametrize("n", [1, 5, 1024, 32000, 128256, 151936])
+def test_argmax_first_maximum(gpu, oracle, n):
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    out = torch.full((1,), -1, dtype=torch.int32, device=gpu)
+    ops.argmax(dev(x, gpu), out)
+    assert int(host(out)[0]) == oracle.argmax(x)
+    assert ops.argmax_host(dev(x, gpu)) == oracle.argmax(x)
+    if n >= 5:
+        # ties: lowest index wins (argmax_sampler.cpp:7, cuda/argmax_kernel.cu:13-18)
+        x[:] = -1.0
+        idx = sorted(rng.choice(n, size=3, replace=False).tolist())
+        x[idx] = 2.5
+        ops.argmax(dev(x, gpu), out)
+        assert int(host(out)[0]) == idx[0] == oracle.argmax(x)
+
+
+# ---------------------------------------------------------------- RoPE + sin/cos cache
+@pytest.mark.parametrize("hs,theta,seq", [(64, 500000.0, 4096), (128, 10000.0, 2048),
+                                          (64, 1000000.0, 1024), (48, 10000.0, 256)])
+def test_sincos_cache_vs_libm(gpu, oracle, hs, theta, seq):
+    from kuiperllama_amd import ops
+    s = torch.empty(seq, hs, device=gpu)
+    c = torch.empty(seq, hs, device=gpu)
+    ops.sincos_cache(hs, seq, theta, s, c)
+    so, co = oracle.sincos_cache(hs, seq, theta)
+    hs_, hc_ = host(s), host(c)
+    # fp64-evaluated-then-rounded vs glibc float functions: identical up to last-bit rounding
+    assert np.abs(hs_ - so).max() <= 1.2e-7 and np.abs(hc_ - co).max() <= 1.2e-7
+    assert (hs_ != so).mean() < 0.05 and (hc_ != co).mean() < 0.05  # glibc sinf is not always correctly rounded
+
+
+def test_sincos_long_context_row(gpu, oracle):
+    """Row 131071 of Llama-3.2's table: the fp32 product pos*freq must be formed like the CPU
+    reference, otherwise sin/cos differ at the 1e-3 level."""
+    from kuiperllama_amd import ops
+    hs, seq, theta = 64, 131072, 500000.0
+    s = torch.empty(seq, hs, device=gpu)
+    c = torch.empty(seq, hs, device=gpu)
+    ops.sincos_cache(hs, seq, theta, s, c)
+    so, co = oracle.sincos_cache(hs, seq, theta)
+    assert np.abs(host(s[-64:]) - so[-64:]).max() <= 1.2e-7
+    assert np.abs(host(c[-64:]) - co[-64:]).max() <= 1.2e-7
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("dim,kv_dim,hs", [(2048, 512, 64), (4096, 4096, 128), (896, 128, 64),
+                                           (288, 288, 48)])
+def test_rope_vs_oracle(gpu, oracle, mode, dim, kv_dim, hs):
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(dim + mode)
+    seq = 300
+    so, co = oracle.sincos_cache(hs, seq, 10000.0 if mode == 0 else 500000.0)
+    q = rng.standard_normal(dim).astype(np.float32)
+    k = rng.standard_normal(kv_dim).astype(np.float32)
+    for pos in (0, 1, 127, 299):
+        qd, kd = dev(q, gpu), dev(k, gpu)
+        ops.rope(qd, kd, pos, dev(so, gpu), dev(co, gpu), hs, mode)
+        qo, ko = oracle.rope(q, k, pos, so, co, hs, mode)
+        # reference's (commented) RoPE test used 1e-3; fma contraction only: 1e-6 holds
+        np.testing.assert_allclose(host(qd), qo, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host(kd), ko, rtol=0, atol=1e-6)
+        # device-scalar position form (graph-capturable)
+        qd2, kd2 = dev(q, gpu), dev(k, gpu)
+        ops.rope(qd2, kd2, torch.tensor([pos], dtype=torch.int32, device=gpu), dev(so, gpu),
+                 dev(co, gpu), hs, mode)
+        assert np.array_equal(host(qd2), host(qd)) and np.array_equal(host(kd2), host(kd))
+
+
+# ---------------------------------------------------------------- attention
+@pytest.mark.parametrize("heads,kv_heads,hs,seq,layers", [
+    (32, 8, 64, 256, 2),     # Llama-3.2-1B geometry
+    (32, 32, 128, 192, 2),   # Llama-2-7B geometry
+    (14, 2, 64, 160, 3),     # Qwen2.5-0.5B geometry (kv_mul = 7)
+    (6, 6, 48, 256, 2),      # stories15M geometry (head_size 48: 12 of 16 lanes active)
+])
+def test_mha_vs_oracle(gpu, oracle, heads, kv_heads, hs, seq, layers):
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(heads * 100 + hs)
+    kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+    kc = rng.standard_normal((layers, seq, kv_dim)).astype(np.float32)
+    vc = rng.standard_normal((layers, seq, kv_dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    kcd, vcd, qd = dev(kc, gpu), dev(vc, gpu), dev(q, gpu)
+    for layer in range(layers):
+        for pos in (0, 1, 15, 16, 63, 127, seq - 1):
+            out = torch.full((dim,), float("nan"), device=gpu)
+            score = torch.zeros(heads, seq, device=gpu)
+            ops.mha(pos, heads, layer, seq, kv_dim, kv_mul, hs, out, qd, score, kcd, vcd)
+            oo, so = oracle.mha(pos, heads, layer, seq, kv_dim, kv_mul, hs, q, kc, vc,
+                                acc=oracle.ACC_F64)
+            np.testing.assert_allclose(host(out), oo, rtol=0, atol=2e-5)
+            # probabilities are left in the score tensor like the reference
+            np.testing.assert_allclose(host(score)[:, : pos + 1], so[:, : pos + 1], rtol=0,
+                                       atol=2e-6)
+
+
+def test_mha_long_context_multi_chunk(gpu, oracle):
+    """pos beyond one LDS score chunk (2048) exercises the running-max rescale; a spiked key in
+    a LATER chunk forces the rescale branch (guide §5.4 rule 26)."""
+    from kuiperllama_amd import ops
+    heads, kv_heads, hs, seq = 8, 2, 64, 6000
+    rng = np.random.default_rng(77)
+    kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+    kc = rng.standard_normal((1, seq, kv_dim)).astype(np.float32)
+    vc = rng.standard_normal((1, seq, kv_dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    kc[0, 4500, :hs] = 3.0 * q[:hs]  # head 0..3 share kv head 0: huge score at t=4500
+    for pos in (2047, 2048, 4499, 4500, 5999):
+        out = torch.full((dim,), float("nan"), device=gpu)
+        score = torch.zeros(heads, seq, device=gpu)
+        ops.mha(torch.tensor([pos], dtype=torch.int32, device=gpu), heads, 0, seq, kv_dim, kv_mul,
+                hs, out, dev(q, gpu), score, dev(kc, gpu), dev(vc, gpu))
+        oo, so = oracle.mha(pos, heads, 0, seq, kv_dim, kv_mul, hs, q, kc, vc, acc=oracle.ACC_F64)
+        np.testing.assert_allclose(host(out), oo, rtol=0, atol=3e-5)
+        np.testing.assert_allclose(host(score)[:, : pos + 1], so[:, : pos + 1], rtol=0, atol=3e-6)
+
+
+# ---------------------------------------------------------------- CPU-only helpers of the reference
+def test_softmax_scale_scalesum(gpu, oracle):
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(9)
+    for n in (1, 7, 128, 5000):
+        x = (4 * rng.standard_normal(n)).astype(np.float32)
+        xd = dev(x, gpu)
+        ops.softmax_(xd)
+        np.testing.assert_allclose(host(xd), oracle.softmax(x), rtol=0, atol=1e-6)
+    x = rng.standard_normal(1000).astype(np.float32)
+    xd = dev(x, gpu)
+    ops.scale_(0.125, xd)
+    assert np.array_equal(host(xd), x * np.float32(0.125))
+    # scale_sum: out += sum_t s[t] * V[t*stride : +size]
+    size, stride, pos = 64, 512, 40
+    v = rng.standard_normal((pos + 1) * stride).astype(np.float32)
+    s = rng.random(pos + 1, dtype=np.float32)
+    out = torch.zeros(size, device=gpu)
+    ops.scale_sum(dev(v, gpu), dev(s, gpu), out, pos, size, stride)
+    ref = (s[:, None].astype(np.float64) * v.reshape(pos + 1, stride)[:, :size]).sum(0)
+    np.testing.assert_allclose(host(out), ref, rtol=0, atol=1e-5)

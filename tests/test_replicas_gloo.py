@@ -1,0 +1,78 @@
+"""N>1 path = independent replicas + timing protocol (kuiperllama_amd/replicas.py), covered with
+world_size-2 gloo processes on CPU.  The per-replica workload here is the CPU oracle decoding a
+tiny golden model (the HIP path needs a GPU); what is under test is the protocol: barrier on
+both sides, max over ranks, aggregate = world*steps / max wall, identical tokens on every
+replica (same seed/prompt)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import time
+    from conftest import load_golden
+    from kuiperllama_amd import replicas
+    from oracle import oracle as O
+    O.set_threads(1)
+    r, w, lr = replicas.init_from_env("gloo")
+    assert (r, w, lr) == (rank, world, rank)
+    spec, img, toks, _ = load_golden("ref_llama_gqa_tied")
+    om = O.OracleModel.from_spec(img, spec)
+    out = {}
+
+    def run():
+        out["words"] = om.generate([int(t) for t in toks[:2]], 16)
+        time.sleep(0.05 * (rank + 1))  # uneven replicas: the max must win
+
+    wall, agg = replicas.timed_replica_run(run, 16, w, torch.device("cpu"), lambda: None)
+    q.put((rank, wall, agg, out["words"]))
+    replicas.shutdown(w)
+
+
+@pytest.mark.timeout(120)
+def test_two_replicas_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    (r0, w0, a0, words0), (r1, w1, a1, words1) = res
+    assert words0 == words1 and len(words0) == 16   # replicas decode the same tokens
+    assert w0 == w1                                  # max over ranks is shared
+    assert w0 >= 0.1                                 # the slower replica (0.1 s sleep) dominates
+    assert abs(a0 - world * 16 / w0) < 1e-9 and a0 == a1
+
+
+def test_single_process_path_needs_no_process_group():
+    sys.path.insert(0, ROOT)
+    from kuiperllama_amd import replicas
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert replicas.init_from_env("gloo") == (0, 1, 0)
+    wall, agg = replicas.timed_replica_run(lambda: None, 10, 1, torch.device("cpu"), lambda: None)
+    assert wall > 0 and abs(agg - 10 / wall) < 1e-6
+    replicas.shutdown(1)
