@@ -86,9 +86,24 @@ def timed_generate(m, steps, warmup, world, dev):
 def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s):
     """Oracle (port of the reference CPU backend) on this host, all cores, bounded sample."""
     from oracle import oracle as O
-    threads = os.cpu_count() or 1
-    O.set_threads(threads)
     om = O.OracleModel.from_spec(img_host, spec, cache_len=max(256, max_tokens + 1))
+    # pick the OpenMP team size by a 1-token calibration per candidate (a DRAM-bound GEMV stops
+    # scaling long before 256 SMT threads; cgroup quotas can make nproc a lie)
+    eff = O.effective_cpus()
+    cands = sorted({c for c in (eff, eff // 2, 64, 32, 16, 8) if 1 <= c <= eff}, reverse=True)
+    best, threads = None, cands[0]
+    for c in cands:
+        O.set_threads(c)
+        om.forward(PROMPT[0], 0)  # warm (page-in) then time one token
+        t = time.perf_counter()
+        om.forward(PROMPT[0], 0)
+        dt1 = time.perf_counter() - t
+        log(f"[bench] cpu calibration: {c} threads -> {dt1 * 1e3:.1f} ms/token")
+        if best is None or dt1 < best:
+            best, threads = dt1, c
+        if dt1 > 4.0:
+            break
+    O.set_threads(threads)
     # time token by token so the sample can stop at the budget
     seq = list(PROMPT)
     t0 = time.perf_counter()
@@ -114,7 +129,10 @@ def load_traffic(kernel_key):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(kernel_key)
+            ent = json.load(f).get(kernel_key)
+            # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x1024 x2 on gfx950
+            # + WRITE_SIZE x1024), summarised by tools/rocpd_summary.py
+            return float(ent["hbm_bytes"]) if ent else None
     except Exception:
         return None
 

@@ -588,6 +588,8 @@ extern "C" int kh_model_create_from_device_weights(const int32_t* h_header,
                                                    size_t weight_nbytes,
                                                    const kh_model_opts* opts, kh_model** out) {
   if (!d_weight_data || !kh_aligned16(d_weight_data)) return KH_ERR_INVALID_ARG;
+  if (!out) return KH_ERR_INVALID_ARG;
+  *out = nullptr;
   kh_model* m = nullptr;
   int rc = new_model(h_header, opts, &m);
   if (rc != KH_OK) return rc;
@@ -603,8 +605,9 @@ extern "C" int kh_model_create_from_device_weights(const int32_t* h_header,
   rc = finish_create(m);
   if (rc != KH_OK) {
     kh_model_destroy(m);
-    *out = nullptr;
+    m = nullptr;
   }
+  *out = m;
   return rc;
 }
 
@@ -615,6 +618,7 @@ extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbyte
   if (nbytes < hdr) return KH_ERR_FORMAT;
   int32_t header[8] = {0};
   memcpy(header, h_image, hdr);
+  *out = nullptr;
   kh_model* m = nullptr;
   int rc = new_model(header, opts, &m);
   if (rc != KH_OK) return rc;
@@ -641,8 +645,9 @@ extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbyte
   rc = finish_create(m);
   if (rc != KH_OK) {
     kh_model_destroy(m);
-    *out = nullptr;
+    m = nullptr;
   }
+  *out = m;
   return rc;
 }
 
