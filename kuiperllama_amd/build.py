@@ -60,3 +60,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+
+
+ADAPTER_TEST_SRC = os.path.normpath(os.path.join(_PKG, "..", "tests", "cpp", "test_adapter.cpp"))
+ADAPTER_TEST_BIN = os.path.join(LIB_DIR, "test_adapter")
+
+
+def build_adapter_test(force: bool = False) -> str:
+    """C++ host-side test of include/kuiper_hip_adapter.hpp, linked against the C-ABI .so."""
+    build_lib()
+    inc = os.path.normpath(os.path.join(_PKG, "..", "include"))
+    deps = [ADAPTER_TEST_SRC, os.path.join(inc, "kuiper_hip_adapter.hpp"),
+            os.path.join(inc, "kuiper_hip.h"), LIB_PATH]
+    if (not force and os.path.exists(ADAPTER_TEST_BIN)
+            and all(os.path.getmtime(d) <= os.path.getmtime(ADAPTER_TEST_BIN) for d in deps)):
+        return ADAPTER_TEST_BIN
+    subprocess.check_call([_hipcc(), "-std=c++17", "-O2", f"-I{inc}", ADAPTER_TEST_SRC, "-o",
+                           ADAPTER_TEST_BIN, f"-L{LIB_DIR}", "-lkuiper_hip",
+                           "-Wl,-rpath,$ORIGIN"])
+    return ADAPTER_TEST_BIN
