@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libkuiper_hip.so")
+LIB_PATH = os.environ.get("KH_LIB") or os.path.join(_PKG, "lib", "libkuiper_hip.so")  # KH_LIB: experiment builds
 
 # every symbol include/kuiper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [

@@ -142,3 +142,93 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
     for (int t = tid; t < nT; t += KH_WG) score_out[t] = expf(score_out[t] - m_run) / inv_l;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Low-latency variant for the fused decode step (no score output).  At decode positions of a
+// few hundred the K/V bytes are tiny (<= 64 KiB per head) and the kernel is pure latency, so:
+//  * q, K and V loads of a batch of 4 timesteps per lane-group are all issued up front — ONE
+//    memory round trip instead of K-then-V;
+//  * every G-lane group keeps its own running (max, sum, o) in registers (flash-style), so
+//    there is no score buffer and no workgroup-wide max/sum pass; the q.k reduction is DPP;
+//  * groups are merged once at the end: permlane swaps inside the wave, one LDS exchange across
+//    the 4 waves (2 barriers in the whole kernel).
+// G = lanes per timestep = pow2 >= hs/4, must be 16, 32 or 64 (hs 33..256).
+#define KH_ATTN_UB 4
+static inline size_t attn_fast_lds_bytes(int head_size) {
+  return (size_t)(8 + 8 + KH_WAVES_PER_WG * head_size) * sizeof(float);
+}
+template <int G>
+__device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ q_h,
+                                                      const float* __restrict__ k_base,
+                                                      const float* __restrict__ v_base,
+                                                      int kv_stride, int hs, int pos,
+                                                      float* __restrict__ out_h, float* smem) {
+  static_assert(G == 16 || G == 32 || G == 64, "G must be 16, 32 or 64");
+  constexpr int TPI = KH_WG / G;
+  float* red = smem;          // [8]
+  float* lpart = smem + 8;    // [8]
+  float* opart = smem + 16;   // [4][hs]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tg = tid / G, dl = tid - tg * G;
+  const int hs4 = hs >> 2;
+  const bool active = dl < hs4;
+  const int stride4 = kv_stride >> 2;
+  const f32x4* K4 = (const f32x4*)k_base;
+  const f32x4* V4 = (const f32x4*)v_base;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int nT = pos + 1;
+  const float scale = 1.0f / sqrtf((float)hs);
+  const f32x4 q4 = active ? ((const f32x4*)q_h)[dl] : zero4;
+
+  float m = -INFINITY, l = 0.f;
+  f32x4 o = zero4;
+  for (int tb = tg; tb < nT; tb += TPI * KH_ATTN_UB) {
+    f32x4 kv[KH_ATTN_UB], vv[KH_ATTN_UB];
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_UB; ++u) {
+      const int t = tb + u * TPI;
+      const int tt = t < nT ? t : nT - 1;
+      kv[u] = active ? K4[(size_t)tt * stride4 + dl] : zero4;
+      vv[u] = active ? V4[(size_t)tt * stride4 + dl] : zero4;
+    }
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_UB; ++u) {
+      const int t = tb + u * TPI;
+      const float s = group_sum<G>(fma4(q4, kv[u], 0.f)) * scale;  // all lanes: DPP, no branch
+      if (t < nT) {
+        const float m_new = fmaxf(m, s);
+        const float alpha = expf(m - m_new);  // exp(-inf) = 0 on the first timestep
+        const float p = expf(s - m_new);
+        l = l * alpha + p;
+        o.x = __builtin_fmaf(p, vv[u].x, o.x * alpha);
+        o.y = __builtin_fmaf(p, vv[u].y, o.y * alpha);
+        o.z = __builtin_fmaf(p, vv[u].z, o.z * alpha);
+        o.w = __builtin_fmaf(p, vv[u].w, o.w * alpha);
+        m = m_new;
+      }
+    }
+  }
+  // ---- merge the TPI groups: common max, rescale, sum ------------------------------------
+  float mw = across_groups_max<G>(m);
+  if (lane == 0) red[wave] = mw;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float f = expf(m - M);  // groups that saw no timestep have m = -inf -> 0
+  l = across_groups_sum<G>(l * f);
+  o.x = across_groups_sum<G>(o.x * f);
+  o.y = across_groups_sum<G>(o.y * f);
+  o.z = across_groups_sum<G>(o.z * f);
+  o.w = across_groups_sum<G>(o.w * f);
+  if (lane < G && active) ((f32x4*)(opart + wave * hs))[dl] = o;
+  if (lane == 0) lpart[wave] = l;
+  __syncthreads();
+  if (tid < hs) {
+    float r = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_PER_WG; ++w) {
+      r += opart[w * hs + tid];
+      L += lpart[w];
+    }
+    out_h[tid] = r / L;
+  }
+}

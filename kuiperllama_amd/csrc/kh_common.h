@@ -33,16 +33,101 @@ __device__ __forceinline__ T ld_nt(const T* p) {
   return __builtin_nontemporal_load(p);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, KH_WAVE);
+// ---- wave64 cross-lane reductions without LDS ----------------------------------------------
+// hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-pipe instruction, ~50+ cycles each and six
+// of them in a dependent chain per reduction).  DPP quad/row permutes + the gfx950
+// v_permlane16/32_swap do the same butterfly on the VALU: xor1, xor2 (quad_perm), half-mirror
+// (= xor4 once quads are uniform), mirror (= xor8), permlane16_swap (rows 0<->1, 2<->3),
+// permlane32_swap (halves).  Pairing is identical to an xor butterfly, so sums are bitwise
+// the same as the shuffle version.
+#define KH_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define KH_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define KH_DPP_HALF_MIRROR 0x141  // lane i <-> 7-i within 8
+#define KH_DPP_MIRROR 0x140       // lane i <-> 15-i within 16
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// v_permlane16_swap(A, B): odd rows of A <-> even rows of B (row = 16 lanes).  With A = B = v
+// the two results are {own row's value, partner row's value} in some order in EVERY lane, so a
+// commutative combine of r[0], r[1] is the xor-16 butterfly step.  Same for 32-lane halves.
+#define KH_SWAP16(v, a, b)                                                     \
+  do {                                                                         \
+    const int _i = __builtin_bit_cast(int, (v));                               \
+    const auto _r = __builtin_amdgcn_permlane16_swap(_i, _i, false, false);    \
+    (a) = __builtin_bit_cast(float, (int)_r[0]);                               \
+    (b) = __builtin_bit_cast(float, (int)_r[1]);                               \
+  } while (0)
+#define KH_SWAP32(v, a, b)                                                     \
+  do {                                                                         \
+    const int _i = __builtin_bit_cast(int, (v));                               \
+    const auto _r = __builtin_amdgcn_permlane32_swap(_i, _i, false, false);    \
+    (a) = __builtin_bit_cast(float, (int)_r[0]);                               \
+    (b) = __builtin_bit_cast(float, (int)_r[1]);                               \
+  } while (0)
+
+__device__ __forceinline__ float xor16_sum(float v) {
+  float a, b;
+  KH_SWAP16(v, a, b);
+  return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float a, b;
+  KH_SWAP32(v, a, b);
+  return a + b;
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  float a, b;
+  KH_SWAP16(v, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  float a, b;
+  KH_SWAP32(v, a, b);
+  return fmaxf(a, b);
+}
+
+// sum over aligned groups of G lanes (G = 1,2,4,...,64); every lane gets its group's sum
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  if (G >= 2) v += dpp_f32<KH_DPP_XOR1>(v);
+  if (G >= 4) v += dpp_f32<KH_DPP_XOR2>(v);
+  if (G >= 8) v += dpp_f32<KH_DPP_HALF_MIRROR>(v);
+  if (G >= 16) v += dpp_f32<KH_DPP_MIRROR>(v);
+  if (G >= 32) v = xor16_sum(v);
+  if (G >= 64) v = xor32_sum(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, KH_WAVE));
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+  if (G >= 2) v = fmaxf(v, dpp_f32<KH_DPP_XOR1>(v));
+  if (G >= 4) v = fmaxf(v, dpp_f32<KH_DPP_XOR2>(v));
+  if (G >= 8) v = fmaxf(v, dpp_f32<KH_DPP_HALF_MIRROR>(v));
+  if (G >= 16) v = fmaxf(v, dpp_f32<KH_DPP_MIRROR>(v));
+  if (G >= 32) v = xor16_max(v);
+  if (G >= 64) v = xor32_max(v);
   return v;
 }
+// sum / max ACROSS the 64/G groups of a wave (lanes with equal lane % G), G >= 16
+template <int G>
+__device__ __forceinline__ float across_groups_sum(float v) {
+  static_assert(G >= 16, "across_groups_* needs G >= 16");
+  if (G <= 16) v = xor16_sum(v);
+  if (G <= 32) v = xor32_sum(v);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float across_groups_max(float v) {
+  static_assert(G >= 16, "across_groups_* needs G >= 16");
+  if (G <= 16) v = xor16_max(v);
+  if (G <= 32) v = xor32_max(v);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
 // Sum over a 256-thread workgroup; every thread gets the result. red = LDS float[4+].
 // Two barriers so `red` can be reused immediately afterwards.
@@ -79,6 +164,9 @@ __device__ __forceinline__ float fma4(f32x4 w, f32x4 x, float acc) {
 
 // 4 packed int8 (one dword) . 4 floats
 __device__ __forceinline__ float dot4_i8(int packed, f32x4 x, float acc) {
+#if defined(KH_EXP_NOCVT) && KH_EXP_NOCVT
+  return __builtin_fmaf(__builtin_bit_cast(float, packed), x.x + x.y + x.z + x.w, acc);
+#endif
   acc = __builtin_fmaf((float)(int8_t)(packed & 0xff), x.x, acc);
   acc = __builtin_fmaf((float)(int8_t)((packed >> 8) & 0xff), x.y, acc);
   acc = __builtin_fmaf((float)(int8_t)((packed >> 16) & 0xff), x.z, acc);

@@ -14,8 +14,9 @@
 //   k_sample merge partials -> next token (or forced prompt token), append to words,
 //            gather its embedding row into x, ++*d_pos    (llama3.cpp:733-745, main.cpp:20-41)
 //
-// All GEMV kernels share kh_gemv.h: a wave streams one ROW PAIR, and the pair is chosen so the
-// epilogue has both operands in registers (RoPE partner rows, (w1,w3) rows, adjacent rows).
+// All GEMV kernels share kh_gemv.h::gemv_pairs: a wave streams one ROW PAIR, and the pair is
+// chosen so the epilogue has both operands in registers (RoPE partner rows, (w1,w3) rows,
+// adjacent rows).
 #pragma once
 #include "kh_attn.h"
 #include "kh_common.h"
@@ -28,28 +29,13 @@ struct KhLin {
   const float* bias;    // Qwen2 q/k/v only
 };
 
-template <bool QUANT, int U>
-__device__ __forceinline__ void row_pair_dot(const KhLin& L, int r0, int r1, int M, int gshift,
-                                             const f32x4* xs, int lane, float& s0, float& s1) {
-  if (QUANT) {
-    const int8_t* w = (const int8_t*)L.w;
-    const int gpr = M >> gshift;
-    dot2_q8<U>((const i32x4*)(w + (size_t)r0 * M), (const i32x4*)(w + (size_t)r1 * M),
-               L.scales + (size_t)r0 * gpr, L.scales + (size_t)r1 * gpr, gshift, xs, M >> 4,
-               lane, s0, s1);
-  } else {
-    const float* w = (const float*)L.w;
-    dot2_f32<U>((const f32x4*)(w + (size_t)r0 * M), (const f32x4*)(w + (size_t)r1 * M), xs,
-                M >> 2, lane, s0, s1);
-  }
-}
-
 template <bool QUANT>
 __device__ __forceinline__ float* lds_red_ptr(f32x4* xs, int M) {
   return (float*)(xs + (QUANT ? 4 * ((M >> 4) + 1) : (M >> 2)));
 }
+// xs | red[4] | comb[8] (split-row partial sums)
 static inline size_t fused_lds_bytes(bool quant, int M) {
-  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 16;
+  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 16 + 32;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -67,23 +53,21 @@ struct KhQkvArgs {
   float eps;
 };
 
-template <bool QUANT, int U>
+template <bool QUANT, int U, int MAXV, int SPLIT>
 __global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
-  stage_vec<true, QUANT>(a.x, a.att_norm, xs, a.dim, a.eps, red);
-  const int pos = *a.d_pos;
   const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * KH_WAVES_PER_WG + (threadIdx.x >> 6);
-  const int nw = gridDim.x * KH_WAVES_PER_WG;
   const int hs = a.head_size, half = hs >> 1;
   const int npq = a.dim >> 1, npk = a.kv_dim >> 1;
   const int total = npq + 2 * npk;
-  const float* srow = a.sin_cache + (size_t)pos * hs;
-  const float* crow = a.cos_cache + (size_t)pos * hs;
-  for (int p = gw; p < total; p += nw) {
-    int which, pp;
+  const Gemv<QUANT, U> g(a.dim, a.gshift);
+  Stager<true, QUANT, MAXV> st(a.x, a.att_norm, a.dim);
+
+  // work item p -> (which projection, row pair, sin/cos column)
+  auto decode = [&](int p, int& which, int& r0, int& r1, int& cidx) {
+    int pp;
     if (p < npq) {
       which = 0;
       pp = p;
@@ -94,7 +78,6 @@ __global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
       which = 2;
       pp = p - npq - npk;
     }
-    int r0, r1, cidx = 0;
     if (which < 2 && a.rope_mode == KH_ROPE_HALF) {
       // cpu/rope_kernel.cpp:18-42: pair (head*hs + j, + hs/2), cache column 2j
       const int head = pp / half, j = pp - head * half;
@@ -107,27 +90,48 @@ __global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
       r1 = r0 + 1;
       cidx = r0 % hs;
     }
+  };
+  auto pair = [&](int p) {
+    int which, r0, r1, cidx;
+    decode(p, which, r0, r1, cidx);
     const KhLin& L = which == 0 ? a.wq : (which == 1 ? a.wk : a.wv);
-    float s0, s1;
-    row_pair_dot<QUANT, U>(L, r0, r1, a.dim, a.gshift, xs, lane, s0, s1);
-    if (lane == 0) {
-      if (L.bias) {  // matmul.cpp:74-77: bias added after the matmul, before RoPE
-        s0 = s0 + L.bias[r0];
-        s1 = s1 + L.bias[r1];
-      }
-      float* dst = which == 0 ? a.q_out
-                              : (which == 1 ? a.kcache_layer : a.vcache_layer) +
-                                    (size_t)pos * a.kv_dim;
-      if (which < 2) {
-        const float fci = srow[cidx], fcr = crow[cidx];
-        const float v0 = s0, v1 = s1;
-        s0 = v0 * fcr - v1 * fci;
-        s1 = v0 * fci + v1 * fcr;
-      }
-      dst[r0] = s0;
-      dst[r1] = s1;
+    return g.rows(L.w, r0, L.w, r1, L.scales, L.scales, a.dim);
+  };
+  const int pos = *a.d_pos;
+  struct Aux {
+    float fci, fcr, b0, b1;
+  };
+  auto pre = [&](int p) {
+    int which, r0, r1, cidx;
+    decode(p, which, r0, r1, cidx);
+    const KhLin& L = which == 0 ? a.wq : (which == 1 ? a.wk : a.wv);
+    Aux x;
+    x.fci = a.sin_cache[(size_t)pos * hs + cidx];
+    x.fcr = a.cos_cache[(size_t)pos * hs + cidx];
+    x.b0 = L.bias ? L.bias[r0] : 0.f;
+    x.b1 = L.bias ? L.bias[r1] : 0.f;
+    return x;
+  };
+  auto epi = [&](int p, float s0, float s1, const Aux& x) {
+    if (lane != 0) return;
+    int which, r0, r1, cidx;
+    decode(p, which, r0, r1, cidx);
+    // matmul.cpp:74-77: bias added after the matmul, before RoPE (x + 0.f is exact)
+    s0 = s0 + x.b0;
+    s1 = s1 + x.b1;
+    float* dst = which == 0 ? a.q_out
+                            : (which == 1 ? a.kcache_layer : a.vcache_layer) +
+                                  (size_t)pos * a.kv_dim;
+    if (which < 2) {
+      const float v0 = s0, v1 = s1;
+      s0 = v0 * x.fcr - v1 * x.fci;
+      s1 = v0 * x.fci + v1 * x.fcr;
     }
-  }
+    dst[r0] = s0;
+    dst[r1] = s1;
+  };
+  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + 4, pair, pre, [&] { st.issue(); },
+                              [&] { st.finish(xs, a.eps, red); }, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -139,7 +143,19 @@ struct KhAttnArgs {
   const int32_t* d_pos;
   int kv_dim, kv_mul, head_size;
 };
+template <int G>
 __global__ __launch_bounds__(KH_WG) void k_attn(const KhAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int pos = *a.d_pos;
+  const int h = blockIdx.x;
+  const size_t head_off = (size_t)(h / a.kv_mul) * a.head_size;
+  attn_head_decode_fast<G>(a.q + (size_t)h * a.head_size, a.kcache_layer + head_off,
+                           a.vcache_layer + head_off, a.kv_dim, a.head_size, pos,
+                           a.out + (size_t)h * a.head_size, (float*)smem_raw);
+}
+
+// head_size <= 32 (tiny test models): the generic LDS-score core of the op-level kernel
+__global__ __launch_bounds__(KH_WG) void k_attn_generic(const KhAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int pos = *a.d_pos;
   const int h = blockIdx.x;
@@ -157,25 +173,29 @@ struct KhGemvResArgs {
   float* x;          // [K] residual stream, updated in place
   int M, K, gshift;
 };
-template <bool QUANT, int U>
+template <bool QUANT, int U, int MAXV, int SPLIT>
 __global__ __launch_bounds__(KH_WG) void k_gemv_res(const KhGemvResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.M);
-  stage_vec<false, QUANT>(a.vec, nullptr, xs, a.M, 0.f, red);
   const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * KH_WAVES_PER_WG + (threadIdx.x >> 6);
-  const int nw = gridDim.x * KH_WAVES_PER_WG;
-  const int npairs = a.K >> 1;  // K even (checked at model build)
-  for (int p = gw; p < npairs; p += nw) {
-    const int r0 = 2 * p, r1 = r0 + 1;
-    float s0, s1;
-    row_pair_dot<QUANT, U>(a.w, r0, r1, a.M, a.gshift, xs, lane, s0, s1);
-    if (lane == 0) {
-      a.x[r0] = a.x[r0] + s0;
-      a.x[r1] = a.x[r1] + s1;
-    }
-  }
+  const Gemv<QUANT, U> g(a.M, a.gshift);
+  Stager<false, QUANT, MAXV> st(a.vec, nullptr, a.M);
+  auto pair = [&](int p) {
+    return g.rows(a.w.w, 2 * p, a.w.w, 2 * p + 1, a.w.scales, a.w.scales, a.M);
+  };
+  struct Aux {
+    float x0, x1;
+  };
+  auto pre = [&](int p) { return Aux{a.x[2 * p], a.x[2 * p + 1]}; };  // residual, fetched early
+  auto epi = [&](int p, float s0, float s1, const Aux& r) {
+    if (lane != 0) return;
+    a.x[2 * p] = r.x0 + s0;
+    a.x[2 * p + 1] = r.x1 + s1;
+  };
+  gemv_pairs<QUANT, U, SPLIT>(g, xs, a.K >> 1 /* K even, checked at model build */, lane,
+                              red + 4, pair, pre, [&] { st.issue(); },
+                              [&] { st.finish(xs, 0.f, red); }, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -187,30 +207,21 @@ struct KhFfn13Args {
   int dim, hidden, gshift;
   float eps;
 };
-template <bool QUANT, int U>
+template <bool QUANT, int U, int MAXV>
 __global__ __launch_bounds__(KH_WG) void k_ffn13(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
-  stage_vec<true, QUANT>(a.x, a.ffn_norm, xs, a.dim, a.eps, red);
   const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * KH_WAVES_PER_WG + (threadIdx.x >> 6);
-  const int nw = gridDim.x * KH_WAVES_PER_WG;
-  for (int r = gw; r < a.hidden; r += nw) {
-    float s0, s1;
-    if (QUANT) {
-      const int gpr = a.dim >> a.gshift;
-      dot2_q8<U>((const i32x4*)((const int8_t*)a.w1.w + (size_t)r * a.dim),
-                 (const i32x4*)((const int8_t*)a.w3.w + (size_t)r * a.dim),
-                 a.w1.scales + (size_t)r * gpr, a.w3.scales + (size_t)r * gpr, a.gshift, xs,
-                 a.dim >> 4, lane, s0, s1);
-    } else {
-      dot2_f32<U>((const f32x4*)((const float*)a.w1.w + (size_t)r * a.dim),
-                  (const f32x4*)((const float*)a.w3.w + (size_t)r * a.dim), xs, a.dim >> 2,
-                  lane, s0, s1);
-    }
+  const Gemv<QUANT, U> g(a.dim, a.gshift);
+  Stager<true, QUANT, MAXV> st(a.x, a.ffn_norm, a.dim);
+  auto pair = [&](int r) { return g.rows(a.w1.w, r, a.w3.w, r, a.w1.scales, a.w3.scales, a.dim); };
+  auto epi = [&](int r, float s0, float s1, const NoAux&) {
     if (lane == 0) a.h[r] = swiglu1(s0, s1);
-  }
+  };
+  gemv_pairs<QUANT, U, 1>(g, xs, a.hidden, lane, nullptr, pair, [](int) { return NoAux{}; },
+                       [&] { st.issue(); },
+                       [&] { st.finish(xs, a.eps, red); }, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,34 +235,36 @@ struct KhClsArgs {
   int dim, vocab, gshift;
   float eps;
 };
-template <bool QUANT, int U>
+template <bool QUANT, int U, int MAXV>
 __global__ __launch_bounds__(KH_WG) void k_cls(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
-  stage_vec<true, QUANT>(a.x, a.final_norm, xs, a.dim, a.eps, red);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw = blockIdx.x * KH_WAVES_PER_WG + wave;
-  const int nw = gridDim.x * KH_WAVES_PER_WG;
-  const int npairs = (a.vocab + 1) >> 1;
+  const Gemv<QUANT, U> g(a.dim, a.gshift);
+  Stager<true, QUANT, MAXV> st(a.x, a.final_norm, a.dim);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int p = gw; p < npairs; p += nw) {
-    const int r0 = 2 * p;
-    const int r1 = r0 + 1 < a.vocab ? r0 + 1 : r0;
-    float s0, s1;
-    row_pair_dot<QUANT, U>(a.wcls, r0, r1, a.dim, a.gshift, xs, lane, s0, s1);
-    if (lane == 0) {
-      a.logits[r0] = s0;
-      amax_merge(bv, bi, s0, r0);
-      if (r1 != r0) {
-        a.logits[r1] = s1;
-        amax_merge(bv, bi, s1, r1);
-      }
+  auto r1_of = [&](int p) { return 2 * p + 1 < a.vocab ? 2 * p + 1 : 2 * p; };
+  auto pair = [&](int p) {
+    return g.rows(a.wcls.w, 2 * p, a.wcls.w, r1_of(p), a.wcls.scales, a.wcls.scales, a.dim);
+  };
+  auto epi = [&](int p, float s0, float s1, const NoAux&) {
+    if (lane != 0) return;
+    const int r0 = 2 * p, r1 = r1_of(p);
+    a.logits[r0] = s0;
+    amax_merge(bv, bi, s0, r0);
+    if (r1 != r0) {
+      a.logits[r1] = s1;
+      amax_merge(bv, bi, s1, r1);
     }
-  }
+  };
+  gemv_pairs<QUANT, U, 1>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
+                          [](int) { return NoAux{}; },
+                       [&] { st.issue(); },
+                       [&] { st.finish(xs, a.eps, red); }, epi);
   // stage-1 argmax: one partial per workgroup (ties -> lowest index)
-  int* redi = (int*)(red + KH_WAVES_PER_WG);
+  int* redi = (int*)(red + KH_WAVES_PER_WG + 8);
   __syncthreads();
   if (lane == 0) {
     red[wave] = bv;

@@ -9,96 +9,301 @@
 // (staged once per workgroup, optionally RMS-normalised on the way in); LDS read bandwidth is
 // ~25x the per-CU HBM rate so re-reading x per row is free.  No LDS round trip for the
 // weights (MI355X guide: "GEMV / M <= 16 decode weights ... load straight to VGPRs, deep
-// unroll, late vmcnt").  The only cross-lane step is one 6-stage wave reduction per row pair.
+// unroll, late vmcnt").  The only cross-lane step is one DPP wave reduction per row pair.
 //
 // Row PAIRS are the unit because every fused epilogue consumes two outputs together:
 // RoPE rotates (v0,v1), SwiGLU combines (w1.x, w3.x), and plain rows just take (2i, 2i+1).
+//
+// Latency structure (these kernels are 4-25 MB = a few HBM round trips long, so fixed costs
+// dominate): a wave issues the loads of its FIRST row pair before the activation vector is
+// staged (the weights do not depend on it: the x round trip through L2, the RMS reduction and
+// the barrier overlap with the first HBM round trip), and issues the loads of its NEXT pair
+// before reducing/storing the current one, so it always has 2*U KiB in flight.
 #pragma once
 #include "kh_common.h"
 
 // ---------------------------------------------------------------------------------------------
-// fp32 rows.  w0/w1: row base pointers (16-B aligned), xs: x in LDS as float4[M4].
-// Returns the two dot products in every lane.
+// Register tiles: one chunk (U x 1 KiB) of two rows.
 template <int U>
-__device__ __forceinline__ void dot2_f32(const f32x4* __restrict__ w0,
-                                         const f32x4* __restrict__ w1, const f32x4* xs, int M4,
-                                         int lane, float& s0, float& s1) {
-  float a0 = 0.f, a1 = 0.f;
-  for (int c0 = 0; c0 < M4; c0 += KH_WAVE * U) {
-    f32x4 v0[U], v1[U];
+struct RegsF32 {
+  f32x4 v0[U], v1[U];
+};
+template <int U>
+struct RegsQ8 {
+  i32x4 q0[U], q1[U];
+  float g0[U], g1[U];
+};
+
+struct RowsF32 {
+  const f32x4* w0;
+  const f32x4* w1;
+};
+struct RowsQ8 {
+  const i32x4* w0;
+  const i32x4* w1;
+  const float* sc0;  // scale of the row's first group (M % group == 0 on this path)
+  const float* sc1;
+};
+
+template <int U>
+__device__ __forceinline__ void load_chunk(RegsF32<U>& r, const RowsF32& rows, int c0, int M4,
+                                           int lane) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = c0 + u * KH_WAVE + lane;
-      const int cidx = idx < M4 ? idx : 0;  // clamped address, masked below
-      v0[u] = ld_nt(w0 + cidx);
-      v1[u] = ld_nt(w1 + cidx);
-    }
+  for (int u = 0; u < U; ++u) {
+    const int idx = c0 + u * KH_WAVE + lane;
+    const int cidx = idx < M4 ? idx : 0;  // clamped address; masked in fma_chunk
+    r.v0[u] = ld_nt(rows.w0 + cidx);
+    r.v1[u] = ld_nt(rows.w1 + cidx);
+  }
+}
+template <int U>
+__device__ __forceinline__ void fma_chunk(const RegsF32<U>& r, const f32x4* xs, int c0, int M4,
+                                          int lane, float& a0, float& a1) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = c0 + u * KH_WAVE + lane;
-      if (idx < M4) {
-        const f32x4 xv = xs[idx];
-        a0 = fma4(v0[u], xv, a0);
-        a1 = fma4(v1[u], xv, a1);
-      }
+  for (int u = 0; u < U; ++u) {
+    const int idx = c0 + u * KH_WAVE + lane;
+    if (idx < M4) {
+      const f32x4 xv = xs[idx];
+      a0 = fma4(r.v0[u], xv, a0);
+      a1 = fma4(r.v1[u], xv, a1);
     }
   }
-  s0 = wave_sum(a0);
-  s1 = wave_sum(a1);
 }
 
-// ---------------------------------------------------------------------------------------------
 // int8 group-quantised rows (tools/export.py:134-210: int8[K*M] then fp32 scales[K*M/g]).
-// w0/w1: row base pointers as dwordx4 (16 weights per lane per load); sc0/sc1: pointer to the
-// scale of the row's first group (valid because M % group == 0 on this path); gshift =
-// log2(group_size) (group is a power of two >= 16 on this path, so one lane's 16 weights
-// share one scale).  xs: LDS in q8_slot() layout.  Dequant factored per 16-weight run:
+// A lane's dwordx4 = 16 weights of ONE group (group is a power of two >= 16 on this path), so
+// one scale per load; dequant factored per 16-weight run:
 //   sum_i x_i * s_g * w_i  ==  s_g * sum_i x_i * w_i      (reference: cuda/matmul_kernel.cu:73)
+// Experiment switches (tools/exp_int8.sh builds variants; defaults are the shipped path).
+#ifndef KH_SCALE_BPERM
+#define KH_SCALE_BPERM 0  // measured SLOWER than direct scale loads (7B int8: 511 -> 455 tok/s)
+#endif
+#ifndef KH_EXP_NOSCALE
+#define KH_EXP_NOSCALE 0  // skip scale loads (wrong results; upper bound for scale handling)
+#endif
+#ifndef KH_EXP_NOLDS
+#define KH_EXP_NOLDS 0    // skip the LDS reads of x (wrong results; LDS cost upper bound)
+#endif
+#ifndef KH_EXP_NOCVT
+#define KH_EXP_NOCVT 0    // skip int8->f32 conversion (wrong results; VALU cost upper bound)
+#endif
+// Scales: with the exporter's group size 64 (gshift == 6) the U <= 4 loads of a chunk span at most
+// 64 groups, so ONE coalesced dword load per lane fetches all of them (lane l holds the scale of
+// group c0/4 + l) and each lane picks its U scales with ds_bpermute (LDS crossbar, no memory
+// access) — instead of U more VMEM instructions per row, which doubled the vector-memory issue
+// count of the int8 kernels.  Other group sizes keep the direct per-load scale fetch.
 template <int U>
-__device__ __forceinline__ void dot2_q8(const i32x4* __restrict__ w0,
-                                        const i32x4* __restrict__ w1,
-                                        const float* __restrict__ sc0,
-                                        const float* __restrict__ sc1, int gshift,
-                                        const f32x4* xs, int M16, int lane, float& s0,
-                                        float& s1) {
-  float a0 = 0.f, a1 = 0.f;
-  const int plane = M16 + 1;
-  for (int c0 = 0; c0 < M16; c0 += KH_WAVE * U) {
-    i32x4 q0[U], q1[U];
-    float g0[U], g1[U];
+__device__ __forceinline__ void load_chunk(RegsQ8<U>& r, const RowsQ8& rows, int gshift, int c0,
+                                           int M16, int lane) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int idx = c0 + u * KH_WAVE + lane;
+    const int cidx = idx < M16 ? idx : 0;
+    r.q0[u] = ld_nt(rows.w0 + cidx);
+    r.q1[u] = ld_nt(rows.w1 + cidx);
+  }
+  if (KH_SCALE_BPERM && gshift == 6 && U <= 4) {
+    const int ng = M16 >> 2;  // groups per row
+    int gi = (c0 >> 2) + lane;
+    gi = gi < ng ? gi : 0;
+    r.g0[0] = rows.sc0[gi];
+    r.g1[0] = rows.sc1[gi];
+  } else if (KH_EXP_NOSCALE) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) r.g0[u] = r.g1[u] = 1.f;
+  } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = c0 + u * KH_WAVE + lane;
       const int cidx = idx < M16 ? idx : 0;
-      q0[u] = ld_nt(w0 + cidx);
-      q1[u] = ld_nt(w1 + cidx);
       const int gi = (cidx << 4) >> gshift;
-      g0[u] = sc0[gi];
-      g1[u] = sc1[gi];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = c0 + u * KH_WAVE + lane;
-      if (idx < M16) {
-        const f32x4 x0 = xs[idx], x1 = xs[plane + idx], x2 = xs[2 * plane + idx],
-                    x3 = xs[3 * plane + idx];
-        float t0 = 0.f, t1 = 0.f;
-        t0 = dot4_i8(q0[u].x, x0, t0);
-        t0 = dot4_i8(q0[u].y, x1, t0);
-        t0 = dot4_i8(q0[u].z, x2, t0);
-        t0 = dot4_i8(q0[u].w, x3, t0);
-        t1 = dot4_i8(q1[u].x, x0, t1);
-        t1 = dot4_i8(q1[u].y, x1, t1);
-        t1 = dot4_i8(q1[u].z, x2, t1);
-        t1 = dot4_i8(q1[u].w, x3, t1);
-        a0 = __builtin_fmaf(g0[u], t0, a0);
-        a1 = __builtin_fmaf(g1[u], t1, a1);
-      }
+      r.g0[u] = rows.sc0[gi];
+      r.g1[u] = rows.sc1[gi];
     }
   }
-  s0 = wave_sum(a0);
-  s1 = wave_sum(a1);
 }
+template <int U>
+__device__ __forceinline__ void fma_chunk(const RegsQ8<U>& r, const f32x4* xs, int c0, int M16,
+                                          int plane, int gshift, int lane, float& a0, float& a1) {
+  float g0[U], g1[U];
+  if (KH_SCALE_BPERM && gshift == 6 && U <= 4) {
+    // c0 is a multiple of 4 on this path (chunks start at multiples of 64*U or of the split
+    // quantum, see gemv_pairs), so group(c0 + u*64 + lane) - c0/4 = u*16 + lane/4
+    const int raw0 = __builtin_bit_cast(int, r.g0[0]), raw1 = __builtin_bit_cast(int, r.g1[0]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int src = (((c0 & 3) + u * KH_WAVE + lane) >> 2) << 2;  // byte address = 4 * lane id
+      g0[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, raw0));
+      g1[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, raw1));
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      g0[u] = r.g0[u];
+      g1[u] = r.g1[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int idx = c0 + u * KH_WAVE + lane;
+    if (idx < M16) {
+#if KH_EXP_NOLDS
+      const f32x4 x0 = {1.f, 2.f, 3.f, 4.f}, x1 = x0, x2 = x0, x3 = x0;
+#else
+      const f32x4 x0 = xs[idx], x1 = xs[plane + idx], x2 = xs[2 * plane + idx],
+                  x3 = xs[3 * plane + idx];
+#endif
+      float t0 = 0.f, t1 = 0.f;
+      t0 = dot4_i8(r.q0[u].x, x0, t0);
+      t0 = dot4_i8(r.q0[u].y, x1, t0);
+      t0 = dot4_i8(r.q0[u].z, x2, t0);
+      t0 = dot4_i8(r.q0[u].w, x3, t0);
+      t1 = dot4_i8(r.q1[u].x, x0, t1);
+      t1 = dot4_i8(r.q1[u].y, x1, t1);
+      t1 = dot4_i8(r.q1[u].z, x2, t1);
+      t1 = dot4_i8(r.q1[u].w, x3, t1);
+      a0 = __builtin_fmaf(g0[u], t0, a0);
+      a1 = __builtin_fmaf(g1[u], t1, a1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Uniform view over fp32 / int8 weight matrices so the kernels are written once.
+template <bool QUANT, int U>
+struct Gemv;
+
+template <int U>
+struct Gemv<false, U> {
+  using Regs = RegsF32<U>;
+  using Rows = RowsF32;
+  int Mc;  // chunks per row in 16-byte units: M/4
+  __device__ __forceinline__ Gemv(int M, int /*gshift*/) : Mc(M >> 2) {}
+  __device__ __forceinline__ Rows rows(const void* w0_base, int r0, const void* w1_base, int r1,
+                                       const float*, const float*, int M) const {
+    return Rows{(const f32x4*)((const float*)w0_base + (size_t)r0 * M),
+                (const f32x4*)((const float*)w1_base + (size_t)r1 * M)};
+  }
+  // lim: end of this wave's column range in 16-byte units (== Mc unless the row is split)
+  __device__ __forceinline__ void load(Regs& r, const Rows& rw, int c0, int lim, int lane) const {
+    load_chunk<U>(r, rw, c0, lim, lane);
+  }
+  __device__ __forceinline__ void fma(const Regs& r, const f32x4* xs, int c0, int lim, int lane,
+                                      float& a0, float& a1) const {
+    fma_chunk<U>(r, xs, c0, lim, lane, a0, a1);
+  }
+};
+
+template <int U>
+struct Gemv<true, U> {
+  using Regs = RegsQ8<U>;
+  using Rows = RowsQ8;
+  int Mc;  // M/16
+  int gshift;
+  __device__ __forceinline__ Gemv(int M, int gs) : Mc(M >> 4), gshift(gs) {}
+  __device__ __forceinline__ Rows rows(const void* w0_base, int r0, const void* w1_base, int r1,
+                                       const float* s0_base, const float* s1_base, int M) const {
+    const int gpr = M >> gshift;  // groups per row
+    return Rows{(const i32x4*)((const int8_t*)w0_base + (size_t)r0 * M),
+                (const i32x4*)((const int8_t*)w1_base + (size_t)r1 * M),
+                s0_base + (size_t)r0 * gpr, s1_base + (size_t)r1 * gpr};
+  }
+  __device__ __forceinline__ void load(Regs& r, const Rows& rw, int c0, int lim, int lane) const {
+    load_chunk<U>(r, rw, gshift, c0, lim, lane);
+  }
+  __device__ __forceinline__ void fma(const Regs& r, const f32x4* xs, int c0, int lim, int lane,
+                                      float& a0, float& a1) const {
+    fma_chunk<U>(r, xs, c0, lim, Mc + 1, gshift, lane, a0, a1);
+  }
+};
+
+// Pipelined row-pair loop shared by every GEMV kernel.
+//   PAIR(p)   -> Rows for work item p                     (pure address arithmetic)
+//   ISSUE()   -> issue the loads of the activation vector  (registers, no wait)
+//   FINISH()  -> norm + write to LDS                        (contains the barriers)
+//   EPI(p, s0, s1) -> epilogue with the two dot products   (called by every lane; lane 0 stores)
+// Order of VMEM issue: x first, then the first weight chunk.  vmcnt retires in order, so the
+// x values can be consumed (s_waitcnt vmcnt(#weight loads)) while the weights are still in
+// flight; the reverse order would make the staging wait for the whole first chunk.
+//   PRE(p)    -> small struct of epilogue operands (bias, sin/cos, residual) fetched EARLY, right
+//                behind the pair's weight loads, so the epilogue has no dependent load left
+//
+// SPLIT (1, 2 or 4): waves of a workgroup that share one row pair, each streaming 1/SPLIT of the
+// columns; partial sums are combined through LDS in fixed order (deterministic).  Used when a
+// matrix has too few rows to put >= ~4096 waves in flight (w2: 1024 pairs of 32 KiB rows), where
+// one wave per pair leaves 4 waves per CU and no load/compute overlap.  comb = LDS float[8].
+template <bool QUANT, int U, int SPLIT, class PairFn, class PreFn, class IssueFn, class FinishFn,
+          class EpiFn>
+__device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4* xs, int total,
+                                           int lane, float* comb, PairFn&& PAIR, PreFn&& PRE,
+                                           IssueFn&& ISSUE, FinishFn&& FINISH, EpiFn&& EPI) {
+  static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
+  constexpr int PPW = KH_WAVES_PER_WG / SPLIT;  // pairs per workgroup per iteration
+  const int wave = threadIdx.x >> 6;
+  const int part = wave & (SPLIT - 1);
+  const int gp = blockIdx.x * PPW + wave / SPLIT;
+  const int np = gridDim.x * PPW;
+  const int step = KH_WAVE * U;
+  // column quantum per part, multiple of 4 chunks so an int8 part starts on a group boundary
+  const int Q = (((g.Mc + SPLIT - 1) / SPLIT) + 3) & ~3;
+  const int cb = part * Q;
+  const int ce = cb + Q < g.Mc ? cb + Q : g.Mc;
+  const int p0 = gp < total ? gp : 0;
+  typename Gemv<QUANT, U>::Regs regs;
+  typename Gemv<QUANT, U>::Rows cur = PAIR(p0);
+  ISSUE();
+  __builtin_amdgcn_sched_barrier(0);  // keep the x loads ahead of the weight loads in the queue
+  // unconditional (an idle wave re-reads pair 0): a branch here would make the compiler merge
+  // the vmcnt state of both paths and wait vmcnt(0) — i.e. for the weights — before using x.
+  // The loads stay in flight across the staging barriers.
+  g.load(regs, cur, cb, ce, lane);
+  auto aux = PRE(p0);
+  FINISH();
+  const int iters = (total + np - 1) / np;  // uniform trip count: the SPLIT path has barriers
+  for (int it = 0; it < iters; ++it) {
+    const int p = gp + it * np;
+    const bool valid = p < total;  // uniform per wave
+    float a0 = 0.f, a1 = 0.f;
+    if (valid) {
+      for (int c0 = cb;;) {
+        g.fma(regs, xs, c0, ce, lane, a0, a1);
+        c0 += step;
+        if (c0 >= ce) break;
+        g.load(regs, cur, c0, ce, lane);
+      }
+    }
+    const int pn = p + np;
+    auto aux_next = aux;
+    if (pn < total) {  // next pair's first chunk is in flight during the reduction + epilogue
+      cur = PAIR(pn);
+      g.load(regs, cur, cb, ce, lane);
+      aux_next = PRE(pn);
+    }
+    float s0 = wave_sum(a0), s1 = wave_sum(a1);
+    if constexpr (SPLIT == 1) {
+      if (valid) EPI(p, s0, s1, aux);
+    } else {
+      if (lane == 0) {
+        comb[2 * wave] = s0;
+        comb[2 * wave + 1] = s1;
+      }
+      __syncthreads();
+      if (valid && part == 0) {
+        s0 = comb[2 * wave];
+        s1 = comb[2 * wave + 1];
+#pragma unroll
+        for (int k = 1; k < SPLIT; ++k) {
+          s0 += comb[2 * (wave + k)];
+          s1 += comb[2 * (wave + k) + 1];
+        }
+        EPI(p, s0, s1, aux);
+      }
+      __syncthreads();
+    }
+    aux = aux_next;
+  }
+}
+struct NoAux {};
 
 // ---------------------------------------------------------------------------------------------
 // Stage a vector into LDS (all 256 threads), optionally RMS-normalising it on the way:
@@ -138,3 +343,68 @@ __device__ __forceinline__ void stage_vec(const float* __restrict__ x,
   }
   __syncthreads();
 }
+
+// Two-phase staging used by gemv_pairs: issue() puts MAXV float4 per thread of x (and of the
+// norm weight) in flight, finish() reduces / normalises / writes LDS.  MAXV is a COMPILE-TIME
+// choice (straight-line code between the x loads and their use, otherwise the compiler's
+// waitcnt merge degrades to vmcnt(0) = "wait for the weights too"):
+//   MAXV = 4  vectors up to 4096 floats (dim of every BASELINE config)
+//   MAXV = 0  any length: single-phase stage_vec after the first weight loads were issued
+template <bool NORM, bool LAYOUT_Q8, int MAXV>
+struct Stager {
+  f32x4 xv[MAXV > 0 ? MAXV : 1];
+  f32x4 wv[(NORM && MAXV > 0) ? MAXV : 1];
+  const float* x;
+  const float* wnorm;
+  int M;
+  __device__ __forceinline__ Stager(const float* x_, const float* wnorm_, int M_)
+      : x(x_), wnorm(wnorm_), M(M_) {}
+  __device__ __forceinline__ void issue() {
+    if constexpr (MAXV > 0) {
+      const int M4 = M >> 2;
+      const f32x4* x4 = (const f32x4*)x;
+      const f32x4* w4 = (const f32x4*)wnorm;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int i = threadIdx.x + v * KH_WG;
+        const int ci = i < M4 ? i : 0;
+        xv[v] = x4[ci];
+        if (NORM) wv[v] = w4[ci];
+      }
+    }
+  }
+  __device__ __forceinline__ void finish(f32x4* xs, float eps, float* red) {
+    if constexpr (MAXV == 0) {
+      stage_vec<NORM, LAYOUT_Q8>(x, wnorm, xs, M, eps, red);
+    } else {
+      const int M4 = M >> 2, M16 = M >> 4;
+      float rs = 1.f;
+      if (NORM) {
+        float ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+          const float t = fma4(xv[v], xv[v], 0.f);
+          ss += (threadIdx.x + v * KH_WG < M4) ? t : 0.f;
+        }
+        ss = block_sum(ss, red);
+        rs = 1.0f / sqrtf(ss / (float)M + eps);
+      }
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int i = threadIdx.x + v * KH_WG;
+        if (i < M4) {
+          f32x4 t = xv[v];
+          if (NORM) {
+            t.x = wv[v].x * (rs * t.x);
+            t.y = wv[v].y * (rs * t.y);
+            t.z = wv[v].z * (rs * t.z);
+            t.w = wv[v].w * (rs * t.w);
+          }
+          xs[LAYOUT_Q8 ? q8_slot(i, M16) : i] = t;
+        }
+      }
+      __syncthreads();
+    }
+  }
+};
+static inline int kh_stage_maxv(int M) { return M <= 4 * 4 * KH_WG ? 4 : 0; }

@@ -8,6 +8,8 @@
 // gfx950 only.  No CPU fallback: every path below launches HIP kernels.
 #include <fcntl.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -52,27 +54,76 @@ struct kh_model {
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
   // launch geometry
-  int grid_qkv = 0, grid_wo = 0, grid_ffn = 0, grid_w2 = 0, grid_cls = 0;
-  int u_dim = 0, u_hid = 0;  // unroll choice for M = dim and M = hidden
+  struct Shape {
+    int u = 2, split = 1, grid = 1;
+  };
+  Shape sh_qkv, sh_wo, sh_ffn, sh_w2, sh_cls;
   // graph
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t gexec = nullptr;
+  // the decode step captured once as a 1-step graph and once as a KH_GRAPH_STEPS-step graph:
+  // consecutive hipGraphLaunch calls leave the GPU idle for ~8 us (measured), so the long
+  // graph amortises that gap over several tokens
+  hipGraph_t graph = nullptr, graphN = nullptr;
+  hipGraphExec_t gexec = nullptr, gexecN = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 namespace {
 
-int pick_u(bool quant, int M) {
-  const int per_lane = quant ? (M / 16 + KH_WAVE - 1) / KH_WAVE : (M / 4 + KH_WAVE - 1) / KH_WAVE;
-  if (quant) return per_lane >= 3 ? 4 : 2;
-  return per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
-}
-
-int grid_for(int nitems) {
-  int g = (nitems + KH_WAVES_PER_WG - 1) / KH_WAVES_PER_WG;
-  if (g < 1) g = 1;
-  if (g > 1024) g = 1024;
-  return g;
+// Launch shape of one GEMV: rows are processed as `pairs` work items of two M-long rows.
+//  split: waves sharing a pair (1/2/4) — raised while the launch has < 4096 waves and each wave
+//         would still stream >= 8 KiB (fp32) / 4 KiB (int8);
+//  u    : 16-byte loads per row per lane in flight (covers the wave's column range when it can);
+//  grid : workgroups, <= 1024 (4 per CU), chosen so every wave gets the same number of items.
+kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const char* env) {
+  kh_model::Shape sh;
+  // tuning hook (tools/sweep_shapes.py): KH_SHAPE_<K>="split,u,grid" overrides the heuristic
+  if (const char* ov = env ? getenv(env) : nullptr) {
+    int sp = 0, u = 0, g = 0;
+    if (sscanf(ov, "%d,%d,%d", &sp, &u, &g) == 3 && (sp == 1 || sp == 2 || sp == 4) &&
+        sp <= max_split && (u == 2 || u == 4 || u == 8) && !(quant && u == 8) && g >= 1 &&
+        g <= 4096) {
+      sh.split = sp;
+      sh.u = u;
+      sh.grid = g;
+      return sh;
+    }
+  }
+  const int elem = quant ? 1 : 4;
+  const int min_bytes = quant ? 4096 : 8192;  // bytes one wave must still stream per pair
+  const long pair_bytes = 2L * M * elem;
+  const int target_waves = pair_bytes >= 16384 ? 8192 : 4096;
+  while (sh.split < max_split && pairs * sh.split < target_waves &&
+         pair_bytes / (sh.split * 2) >= min_bytes)
+    sh.split *= 2;
+  const int Mc = quant ? M / 16 : M / 4;
+  const int per_lane = ((Mc + sh.split - 1) / sh.split + KH_WAVE - 1) / KH_WAVE;
+  if (quant)
+    sh.u = per_lane >= 3 ? 4 : 2;
+  else
+    sh.u = per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
+  const int ppw = KH_WAVES_PER_WG / sh.split;  // pairs per workgroup per iteration
+  const int need = (pairs + ppw - 1) / ppw;
+  // every workgroup re-stages the M-float input vector from L2: keep that below ~75 % of the
+  // weight bytes (matters for w2, whose input is the hidden-sized vector; sweep in
+  // profiles/r1_shape_sweep.md), and never more than 4 workgroups per CU
+  long cap = (long)(0.75 * (double)pairs * (double)pair_bytes / ((double)M * 4.0));
+  if (cap > 1024) cap = 1024;
+  if (cap < 256) cap = 256;
+  if (need <= cap) {
+    sh.grid = need;
+  } else {
+    long best_waste = -1;
+    for (long g = cap; g >= cap / 2; --g) {
+      const long iters = (need + g - 1) / g;
+      const long waste = iters * g - need;
+      if (best_waste < 0 || waste < best_waste) {
+        best_waste = waste;
+        sh.grid = (int)g;
+      }
+      if (waste == 0) break;
+    }
+  }
+  return sh;
 }
 
 int ilog2_exact(int v) {
@@ -83,22 +134,56 @@ int ilog2_exact(int v) {
 }
 
 // ---- fused launches -------------------------------------------------------------------------
-#define KH_DISPATCH_U(KERNEL, QUANT, U, GRID, LDS, STREAM, ARGS)                              \
-  do {                                                                                        \
-    if (QUANT) {                                                                              \
-      if ((U) >= 4)                                                                           \
-        hipLaunchKernelGGL((KERNEL<true, 4>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);    \
-      else                                                                                    \
-        hipLaunchKernelGGL((KERNEL<true, 2>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);    \
-    } else {                                                                                  \
-      if ((U) >= 8)                                                                           \
-        hipLaunchKernelGGL((KERNEL<false, 8>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);   \
-      else if ((U) >= 4)                                                                      \
-        hipLaunchKernelGGL((KERNEL<false, 4>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);   \
-      else                                                                                    \
-        hipLaunchKernelGGL((KERNEL<false, 2>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS);   \
-    }                                                                                         \
+// Template dispatch.  U: 16-byte loads per row in flight per lane; MV: in-register staging depth
+// (kh_stage_maxv of the input length); SP: waves sharing one row pair.
+#define KH_L3(KERNEL, Q, UU, MV, GRID, LDS, STREAM, ARGS) \
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS)
+#define KH_L4(KERNEL, Q, UU, MV, SP, GRID, LDS, STREAM, ARGS) \
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS)
+#define KH_SEL_MV3(KERNEL, Q, UU, MV, ...)                  \
+  do {                                                      \
+    if ((MV) == 4)                                          \
+      KH_L3(KERNEL, Q, UU, 4, __VA_ARGS__);                 \
+    else                                                    \
+      KH_L3(KERNEL, Q, UU, 0, __VA_ARGS__);                 \
   } while (0)
+#define KH_SEL_SP4(KERNEL, Q, UU, MV, SP, ...)              \
+  do {                                                      \
+    if ((SP) == 4)                                          \
+      KH_L4(KERNEL, Q, UU, MV, 4, __VA_ARGS__);             \
+    else if ((SP) == 2)                                     \
+      KH_L4(KERNEL, Q, UU, MV, 2, __VA_ARGS__);             \
+    else                                                    \
+      KH_L4(KERNEL, Q, UU, MV, 1, __VA_ARGS__);             \
+  } while (0)
+#define KH_SEL_MV4(KERNEL, Q, UU, MV, SP, ...)              \
+  do {                                                      \
+    if ((MV) == 4)                                          \
+      KH_SEL_SP4(KERNEL, Q, UU, 4, SP, __VA_ARGS__);        \
+    else                                                    \
+      KH_SEL_SP4(KERNEL, Q, UU, 0, SP, __VA_ARGS__);        \
+  } while (0)
+#define KH_SEL_U(SEL, KERNEL, QUANT, U, ...)                \
+  do {                                                      \
+    if (QUANT) {                                            \
+      if ((U) >= 4)                                         \
+        SEL(KERNEL, true, 4, __VA_ARGS__);                  \
+      else                                                  \
+        SEL(KERNEL, true, 2, __VA_ARGS__);                  \
+    } else {                                                \
+      if ((U) >= 8)                                         \
+        SEL(KERNEL, false, 8, __VA_ARGS__);                 \
+      else if ((U) >= 4)                                    \
+        SEL(KERNEL, false, 4, __VA_ARGS__);                 \
+      else                                                  \
+        SEL(KERNEL, false, 2, __VA_ARGS__);                 \
+    }                                                       \
+  } while (0)
+// kernels without / with the SPLIT parameter
+#define KH_DISPATCH3(KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV3, KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS)
+#define KH_DISPATCH4(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV4, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
 
 void launch_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -122,7 +207,8 @@ void launch_qkv(kh_model* m, int l) {
   a.gshift = m->gshift;
   a.eps = c.rms_eps;
   const bool qn = c.is_quant;
-  KH_DISPATCH_U(k_qkv, qn, m->u_dim, m->grid_qkv, fused_lds_bytes(qn, c.dim), m->stream, a);
+  KH_DISPATCH4(k_qkv, qn, m->sh_qkv.u, kh_stage_maxv(c.dim), m->sh_qkv.split, m->sh_qkv.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 void launch_attn(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -135,8 +221,18 @@ void launch_attn(kh_model* m, int l) {
   a.kv_dim = c.kv_dim;
   a.kv_mul = c.kv_mul;
   a.head_size = c.head_size;
-  hipLaunchKernelGGL(k_attn, dim3(c.head_num), dim3(KH_WG), attn_lds_bytes(c.head_size),
-                     m->stream, a);
+  int G = 1;
+  while (G < c.head_size / 4) G <<= 1;
+  const size_t lds = attn_fast_lds_bytes(c.head_size);
+  if (G <= 16 && c.head_size > 32)
+    hipLaunchKernelGGL(k_attn<16>, dim3(c.head_num), dim3(KH_WG), lds, m->stream, a);
+  else if (G == 32)
+    hipLaunchKernelGGL(k_attn<32>, dim3(c.head_num), dim3(KH_WG), lds, m->stream, a);
+  else if (G == 64)
+    hipLaunchKernelGGL(k_attn<64>, dim3(c.head_num), dim3(KH_WG), lds, m->stream, a);
+  else  // head_size <= 32: generic LDS-score kernel (tiny test models)
+    hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(KH_WG),
+                       attn_lds_bytes(c.head_size), m->stream, a);
 }
 void launch_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -148,7 +244,8 @@ void launch_wo(kh_model* m, int l) {
   a.K = c.dim;
   a.gshift = m->gshift;
   const bool qn = c.is_quant;
-  KH_DISPATCH_U(k_gemv_res, qn, m->u_dim, m->grid_wo, fused_lds_bytes(qn, c.dim), m->stream, a);
+  KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim), m->sh_wo.split, m->sh_wo.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 void launch_ffn13(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -164,7 +261,8 @@ void launch_ffn13(kh_model* m, int l) {
   a.gshift = m->gshift;
   a.eps = c.rms_eps;
   const bool qn = c.is_quant;
-  KH_DISPATCH_U(k_ffn13, qn, m->u_dim, m->grid_ffn, fused_lds_bytes(qn, c.dim), m->stream, a);
+  KH_DISPATCH3(k_ffn13, qn, m->sh_ffn.u, kh_stage_maxv(c.dim), m->sh_ffn.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 void launch_w2(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -176,8 +274,8 @@ void launch_w2(kh_model* m, int l) {
   a.K = c.dim;
   a.gshift = m->gshift;
   const bool qn = c.is_quant;
-  KH_DISPATCH_U(k_gemv_res, qn, m->u_hid, m->grid_w2, fused_lds_bytes(qn, c.hidden_dim),
-                m->stream, a);
+  KH_DISPATCH4(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim), m->sh_w2.split, m->sh_w2.grid,
+               fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
 }
 void launch_cls(kh_model* m) {
   const kh_config& c = m->cfg;
@@ -194,7 +292,8 @@ void launch_cls(kh_model* m) {
   a.eps = c.rms_eps;
   // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
   const bool qn = c.is_quant;
-  KH_DISPATCH_U(k_cls, qn, m->u_dim, m->grid_cls, cls_lds_bytes(qn, c.dim), m->stream, a);
+  KH_DISPATCH3(k_cls, qn, m->sh_cls.u, kh_stage_maxv(c.dim), m->sh_cls.grid, cls_lds_bytes(qn, c.dim),
+               m->stream, a);
 }
 void launch_sample(kh_model* m, int advance, int n_forced) {
   const kh_config& c = m->cfg;
@@ -307,24 +406,30 @@ int ensure_seq_cap(kh_model* m, int n) {
   if ((rc = dalloc(&m->d_words, (size_t)n + 1)) != KH_OK) return rc;
   m->seq_cap = n;
   // the graph captured pointers/capacity: rebuild
-  if (m->gexec) {
-    (void)hipGraphExecDestroy(m->gexec);
-    m->gexec = nullptr;
-  }
-  if (m->graph) {
-    (void)hipGraphDestroy(m->graph);
-    m->graph = nullptr;
-  }
+  if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+  if (m->gexecN) (void)hipGraphExecDestroy(m->gexecN);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  if (m->graphN) (void)hipGraphDestroy(m->graphN);
+  m->gexec = m->gexecN = nullptr;
+  m->graph = m->graphN = nullptr;
   return KH_OK;
 }
 
-int ensure_graph(kh_model* m, int n_forced) {
-  if (m->gexec) return KH_OK;
+#define KH_GRAPH_STEPS 8
+int capture_steps(kh_model* m, int n_forced, int steps, hipGraph_t* g, hipGraphExec_t* ge) {
   KH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-  launch_step_fused(m, /*advance=*/1, n_forced, nullptr);
-  hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
+  for (int i = 0; i < steps; ++i) launch_step_fused(m, /*advance=*/1, n_forced, nullptr);
+  hipError_t e = hipStreamEndCapture(m->stream, g);
   if (e != hipSuccess) return (int)e;
-  KH_CHECK_HIP(hipGraphInstantiate(&m->gexec, m->graph, nullptr, nullptr, 0));
+  KH_CHECK_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+  return KH_OK;
+}
+int ensure_graph(kh_model* m, int n_forced) {
+  int rc;
+  if (!m->gexec && (rc = capture_steps(m, n_forced, 1, &m->graph, &m->gexec)) != KH_OK) return rc;
+  if (!m->gexecN &&
+      (rc = capture_steps(m, n_forced, KH_GRAPH_STEPS, &m->graphN, &m->gexecN)) != KH_OK)
+    return rc;
   return KH_OK;
 }
 
@@ -485,14 +590,12 @@ int finish_create(kh_model* m) {
   KH_ALLOC(m->d_token, 1);
   KH_ALLOC(m->d_next, 1);
   // launch geometry
-  m->u_dim = pick_u(c.is_quant, c.dim);
-  m->u_hid = pick_u(c.is_quant, c.hidden_dim);
-  m->grid_qkv = grid_for((c.dim + 2 * c.kv_dim) / 2);
-  m->grid_wo = grid_for(c.dim / 2);
-  m->grid_ffn = grid_for(c.hidden_dim);
-  m->grid_w2 = grid_for(c.dim / 2);
-  m->grid_cls = grid_for((c.vocab_size + 1) / 2);
-  m->nparts = m->grid_cls;
+  m->sh_qkv = pick_shape(c.is_quant, (c.dim + 2 * c.kv_dim) / 2, c.dim, 2, "KH_SHAPE_QKV");
+  m->sh_wo = pick_shape(c.is_quant, c.dim / 2, c.dim, 4, "KH_SHAPE_WO");
+  m->sh_ffn = pick_shape(c.is_quant, c.hidden_dim, c.dim, 1, "KH_SHAPE_FFN");
+  m->sh_w2 = pick_shape(c.is_quant, c.dim / 2, c.hidden_dim, 4, "KH_SHAPE_W2");
+  m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS");
+  m->nparts = m->sh_cls.grid;
   KH_ALLOC(m->part_val, (size_t)m->nparts);
   KH_ALLOC(m->part_idx, (size_t)m->nparts);
 #undef KH_ALLOC
@@ -523,11 +626,15 @@ int finish_create(kh_model* m) {
   if (lds_need > 160 * 1024) return KH_ERR_UNSUPPORTED;
   if (lds_need > 64 * 1024) {
     const int v = (int)lds_need;
-    (void)hipFuncSetAttribute((const void*)k_gemv_res<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
-    (void)hipFuncSetAttribute((const void*)k_gemv_res<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
-    (void)hipFuncSetAttribute((const void*)k_gemv_res<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
-    (void)hipFuncSetAttribute((const void*)k_gemv_res<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
-    (void)hipFuncSetAttribute((const void*)k_gemv_res<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+#define KH_ATTR(Q, UU, SP)                                                                     \
+  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP>,                             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, v)
+    KH_ATTR(false, 8, 1); KH_ATTR(false, 8, 2); KH_ATTR(false, 8, 4);
+    KH_ATTR(false, 4, 1); KH_ATTR(false, 4, 2); KH_ATTR(false, 4, 4);
+    KH_ATTR(false, 2, 1); KH_ATTR(false, 2, 2); KH_ATTR(false, 2, 4);
+    KH_ATTR(true, 4, 1); KH_ATTR(true, 4, 2); KH_ATTR(true, 4, 4);
+    KH_ATTR(true, 2, 1); KH_ATTR(true, 2, 2); KH_ATTR(true, 2, 4);
+#undef KH_ATTR
   }
   KH_CHECK_HIP(hipEventCreate(&m->ev0));
   KH_CHECK_HIP(hipEventCreate(&m->ev1));
@@ -569,7 +676,9 @@ extern "C" void kh_model_destroy(kh_model* m) {
   if (!m) return;
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+  if (m->gexecN) (void)hipGraphExecDestroy(m->gexecN);
   if (m->graph) (void)hipGraphDestroy(m->graph);
+  if (m->graphN) (void)hipGraphDestroy(m->graphN);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
@@ -777,11 +886,18 @@ extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n
 
   set_state(m, h_prompt[0], 0);
   KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
-  for (int s = 0; s < total_steps; ++s) {
+  for (int s = 0; s < total_steps;) {
     if (exec == KH_EXEC_GRAPH) {
-      KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
+      if (total_steps - s >= KH_GRAPH_STEPS) {
+        KH_CHECK_HIP(hipGraphLaunch(m->gexecN, m->stream));
+        s += KH_GRAPH_STEPS;
+      } else {
+        KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
+        s += 1;
+      }
     } else {
       launch_step_fused(m, 1, n_forced, nullptr);
+      s += 1;
     }
   }
   KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));

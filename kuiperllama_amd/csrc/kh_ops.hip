@@ -84,7 +84,7 @@ extern "C" int kh_scale_f32(float scale, float* x, int32_t n, void* stream) {
 // =============================================================================================
 // matmul fp32 (GEMV).  reference: cuda/matmul_kernel.cu:7-54 = one 128-thread block per row,
 // x re-read from global by every block.  Here: wave per row pair, x staged once per WG in LDS.
-template <int U>
+template <int U, int MAXV>
 __global__ __launch_bounds__(KH_WG) void k_matmul_f32(const float* __restrict__ x,
                                                       const float* __restrict__ w,
                                                       float* __restrict__ y, int M, int K,
@@ -93,22 +93,19 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_f32(const float* __restrict__ 
   f32x4* xs = (f32x4*)smem_raw;
   const int M4 = M >> 2;
   float* red = (float*)(xs + M4);
-  stage_vec<false, false>(x, nullptr, xs, M, 0.f, red);
   const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * KH_WAVES_PER_WG + (threadIdx.x >> 6);
-  const int nw = gridDim.x * KH_WAVES_PER_WG;
-  const int npairs = (K + 1) >> 1;
-  for (int p = gw; p < npairs; p += nw) {
-    const int r0 = 2 * p;
-    const int r1 = r0 + 1 < K ? r0 + 1 : r0;
-    float s0, s1;
-    dot2_f32<U>((const f32x4*)(w + (size_t)r0 * M), (const f32x4*)(w + (size_t)r1 * M), xs, M4,
-                lane, s0, s1);
-    if (lane == 0) {
-      y[r0] = s0 * scale;
-      if (r1 != r0) y[r1] = s1 * scale;
-    }
-  }
+  const Gemv<false, U> g(M, 0);
+  Stager<false, false, MAXV> st(x, nullptr, M);
+  auto r1_of = [&](int p) { return 2 * p + 1 < K ? 2 * p + 1 : 2 * p; };
+  auto pair = [&](int p) { return g.rows(w, 2 * p, w, r1_of(p), nullptr, nullptr, M); };
+  auto epi = [&](int p, float s0, float s1, const NoAux&) {
+    if (lane != 0) return;
+    const int r0 = 2 * p, r1 = r1_of(p);
+    y[r0] = s0 * scale;
+    if (r1 != r0) y[r1] = s1 * scale;
+  };
+  gemv_pairs<false, U, 1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) { return NoAux{}; },
+                       [&] { st.issue(); }, [&] { st.finish(xs, 0.f, red); }, epi);
 }
 
 // any M / any alignment (also M too large for LDS): wave per row, scalar lane-strided loads
@@ -149,19 +146,24 @@ extern "C" int kh_matmul_f32(const float* x, const float* w, float* y, int32_t M
   const size_t lds = (size_t)M * 4 + 16;
   const int grid = gemv_grid((K + 1) / 2);
   const int per_lane = (M / 4 + KH_WAVE - 1) / KH_WAVE;
-  if (per_lane >= 8)
-    hipLaunchKernelGGL(k_matmul_f32<8>, dim3(grid), dim3(KH_WG), lds, s, x, w, y, M, K, scale);
-  else if (per_lane >= 3)
-    hipLaunchKernelGGL(k_matmul_f32<4>, dim3(grid), dim3(KH_WG), lds, s, x, w, y, M, K, scale);
-  else
-    hipLaunchKernelGGL(k_matmul_f32<2>, dim3(grid), dim3(KH_WG), lds, s, x, w, y, M, K, scale);
+#define KH_MM(UU, MV) \
+  hipLaunchKernelGGL((k_matmul_f32<UU, MV>), dim3(grid), dim3(KH_WG), lds, s, x, w, y, M, K, scale)
+  const bool inreg = kh_stage_maxv(M) == 4;
+  if (per_lane >= 8) {
+    if (inreg) KH_MM(8, 4); else KH_MM(8, 0);
+  } else if (per_lane >= 3) {
+    if (inreg) KH_MM(4, 4); else KH_MM(4, 0);
+  } else {
+    KH_MM(2, 4);  // per_lane < 3 implies M <= 512
+  }
+#undef KH_MM
   return kh_launch_status();
 }
 
 // =============================================================================================
 // matmul int8 group-dequant.  reference: cuda/matmul_kernel.cu:56-87 (scalar byte loads, an
 // integer divide and a scale load per element).
-template <int U>
+template <int U, int MAXV>
 __global__ __launch_bounds__(KH_WG) void k_matmul_q8(const float* __restrict__ x,
                                                      const int8_t* __restrict__ w,
                                                      const float* __restrict__ scales,
@@ -171,24 +173,19 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_q8(const float* __restrict__ x
   f32x4* xs = (f32x4*)smem_raw;
   const int M16 = M >> 4;
   float* red = (float*)(xs + 4 * (M16 + 1));
-  stage_vec<false, true>(x, nullptr, xs, M, 0.f, red);
   const int lane = threadIdx.x & 63;
-  const int gw = blockIdx.x * KH_WAVES_PER_WG + (threadIdx.x >> 6);
-  const int nw = gridDim.x * KH_WAVES_PER_WG;
-  const int npairs = (K + 1) >> 1;
-  const int gpr = M >> gshift;  // groups per row
-  for (int p = gw; p < npairs; p += nw) {
-    const int r0 = 2 * p;
-    const int r1 = r0 + 1 < K ? r0 + 1 : r0;
-    float s0, s1;
-    dot2_q8<U>((const i32x4*)(w + (size_t)r0 * M), (const i32x4*)(w + (size_t)r1 * M),
-               scales + (size_t)r0 * gpr, scales + (size_t)r1 * gpr, gshift, xs, M16, lane, s0,
-               s1);
-    if (lane == 0) {
-      y[r0] = s0;
-      if (r1 != r0) y[r1] = s1;
-    }
-  }
+  const Gemv<true, U> g(M, gshift);
+  Stager<false, true, MAXV> st(x, nullptr, M);
+  auto r1_of = [&](int p) { return 2 * p + 1 < K ? 2 * p + 1 : 2 * p; };
+  auto pair = [&](int p) { return g.rows(w, 2 * p, w, r1_of(p), scales, scales, M); };
+  auto epi = [&](int p, float s0, float s1, const NoAux&) {
+    if (lane != 0) return;
+    const int r0 = 2 * p, r1 = r1_of(p);
+    y[r0] = s0;
+    if (r1 != r0) y[r1] = s1;
+  };
+  gemv_pairs<true, U, 1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) { return NoAux{}; },
+                      [&] { st.issue(); }, [&] { st.finish(xs, 0.f, red); }, epi);
 }
 
 // literal restatement of the reference formula for any M/group/alignment
@@ -236,12 +233,16 @@ extern "C" int kh_matmul_q8(const float* x, const int8_t* w8, const float* scale
   const size_t lds = kh_q8_lds_bytes(M) + 16;
   const int grid = gemv_grid((K + 1) / 2);
   const int per_lane = (M / 16 + KH_WAVE - 1) / KH_WAVE;
-  if (per_lane >= 3)
-    hipLaunchKernelGGL(k_matmul_q8<4>, dim3(grid), dim3(KH_WG), lds, s, x, w8, scales, gshift,
-                       y, M, K);
-  else
-    hipLaunchKernelGGL(k_matmul_q8<2>, dim3(grid), dim3(KH_WG), lds, s, x, w8, scales, gshift,
-                       y, M, K);
+#define KH_MMQ(UU, MV)                                                                        \
+  hipLaunchKernelGGL((k_matmul_q8<UU, MV>), dim3(grid), dim3(KH_WG), lds, s, x, w8, scales, gshift, \
+                     y, M, K)
+  const bool inreg = kh_stage_maxv(M) == 4;
+  if (per_lane >= 3) {
+    if (inreg) KH_MMQ(4, 4); else KH_MMQ(4, 0);
+  } else {
+    KH_MMQ(2, 4);  // per_lane < 3 implies M <= 2048
+  }
+#undef KH_MMQ
   return kh_launch_status();
 }
 
