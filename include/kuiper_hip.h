@@ -95,11 +95,24 @@ int kh_sincos_cache_f32(int32_t head_size, int32_t max_seq_len, float theta, flo
 
 /* MHAKernel (kernels_interface.h:22-28; cuda/mha_kernel.cu:47-130, cpu/mha_kernel.cpp:5-61).
  * Decode attention for one query token over the contiguous KV cache; softmax probabilities
- * are left in score[head, 0..pos] like the reference.  Position = *d_pos or pos. */
+ * are left in score[head, 0..pos] like the reference.  Position = *d_pos or pos.
+ * score may be NULL: probabilities are then not materialised and the launch uses the fused
+ * decode path's low-latency kernel (per-lane-group online softmax, one memory round trip). */
 int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num, int32_t layer_index,
                int32_t seq_len, int32_t kv_dim, int32_t kv_mul, int32_t head_size,
                float* mha_out, const float* q, float* score, const float* kcache,
                const float* vcache, void* stream);
+
+/* The decode-path attention kernel with its long-context time split: the grid carries
+ * ceil(seq_len/1024) (<= 16) workgroups per head; positions < 256 use one of them, longer
+ * contexts split the timesteps and the last workgroup to finish merges the partial
+ * (max, sum, o) triples.  `workspace` = kh_mha_decode_workspace_bytes(...) bytes, 16-byte
+ * aligned, ZEROED once before first use (the kernel re-arms it); may be NULL when that is 0. */
+int64_t kh_mha_decode_workspace_bytes(int32_t head_num, int32_t head_size, int32_t seq_len);
+int kh_mha_decode_f32(const int32_t* d_pos, int32_t pos, int32_t head_num, int32_t layer_index,
+                      int32_t seq_len, int32_t kv_dim, int32_t kv_mul, int32_t head_size,
+                      float* mha_out, const float* q, const float* kcache, const float* vcache,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* argmax_kernel_cu (cuda/argmax_kernel.cuh:4; argmax_sampler.cpp:5-13): index of the first
  * maximum.  Device-result form (graph-capturable) and host-result form (synchronises the

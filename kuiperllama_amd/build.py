@@ -79,3 +79,20 @@ def build_adapter_test(force: bool = False) -> str:
                            ADAPTER_TEST_BIN, f"-L{LIB_DIR}", "-lkuiper_hip",
                            "-Wl,-rpath,$ORIGIN"])
     return ADAPTER_TEST_BIN
+
+
+DEMO_SRC = os.path.normpath(os.path.join(_PKG, "..", "tools", "kuiper_demo.cpp"))
+DEMO_BIN = os.path.join(LIB_DIR, "kuiper_demo")
+
+
+def build_demo(force: bool = False) -> str:
+    """Command-line twin of the reference's demo/main.cpp over the C-ABI."""
+    build_lib()
+    inc = os.path.normpath(os.path.join(_PKG, "..", "include"))
+    deps = [DEMO_SRC, os.path.join(inc, "kuiper_hip.h"), LIB_PATH]
+    if (not force and os.path.exists(DEMO_BIN)
+            and all(os.path.getmtime(d) <= os.path.getmtime(DEMO_BIN) for d in deps)):
+        return DEMO_BIN
+    subprocess.check_call([_hipcc(), "-std=c++17", "-O2", f"-I{inc}", DEMO_SRC, "-o", DEMO_BIN,
+                           f"-L{LIB_DIR}", "-lkuiper_hip", "-Wl,-rpath,$ORIGIN"])
+    return DEMO_BIN

@@ -153,16 +153,58 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 //  * groups are merged once at the end: permlane swaps inside the wave, one LDS exchange across
 //    the 4 waves (2 barriers in the whole kernel).
 // G = lanes per timestep = pow2 >= hs/4, must be 16, 32 or 64 (hs 33..256).
+//
+// Long contexts: the grid carries NS workgroups per head ("splits"); at run time the first
+// nact = ceil((pos+1)/TS) of them each take TS timesteps (TS >= 256, so positions < 256 use
+// exactly one workgroup per head and none of the machinery below) and the rest exit.  With
+// nact > 1 every split publishes its unnormalised (M, L, o[hs]) and takes a ticket; the LAST
+// arriver merges all partials — the in-launch split reduction recipe of the CDNA guide
+// (plain stores -> every wave drains vmcnt -> barrier -> one lane: agent release fence + asm
+// vmcnt(0) -> relaxed agent ticket; last arriver: agent acquire -> barrier -> reads), which is
+// placement-independent (splits of a head land on different XCDs) and never waits on another
+// workgroup, so it cannot hang.  The ticket counter is re-armed by the merger.
 #define KH_ATTN_UB 4
+#define KH_ATTN_MIN_TS 256  // timesteps per split before a second split is opened
+#define KH_ATTN_MAX_NS 16
 static inline size_t attn_fast_lds_bytes(int head_size) {
   return (size_t)(8 + 8 + KH_WAVES_PER_WG * head_size) * sizeof(float);
 }
+// splits per head carried by the grid for a cache of `cache_len` rows
+static inline int attn_num_splits(int cache_len) {
+  int ns = (cache_len + 1023) / 1024;
+  if (ns < 1) ns = 1;
+  if (ns > KH_ATTN_MAX_NS) ns = KH_ATTN_MAX_NS;
+  return ns;
+}
+// workspace for the split merge: [heads] int tickets | [heads*NS*2] (M,L) | [heads*NS*hs] o
+static inline size_t attn_ws_bytes(int heads, int head_size, int ns) {
+  return ns <= 1 ? 0
+                 : (size_t)heads * sizeof(int) + (size_t)heads * ns * (2 + head_size) * sizeof(float);
+}
+
+struct AttnSplitWs {
+  int* cnt;        // [heads]   arrival tickets, zero between launches
+  float* ml;       // [heads, NS, 2]
+  float* o;        // [heads, NS, hs]
+};
+__host__ __device__ static inline AttnSplitWs attn_ws_carve(void* ws, int heads, int head_size,
+                                                             int ns) {
+  AttnSplitWs w;
+  w.cnt = (int*)ws;
+  w.ml = (float*)(w.cnt + heads);
+  w.o = w.ml + (size_t)heads * ns * 2;
+  (void)head_size;
+  return w;
+}
+
+// Attention of head h over timesteps [t_begin, t_end): leaves, for threads tid < hs, the
+// unnormalised output r = sum_t exp(s_t - M) v_t[tid] and L = sum_t exp(s_t - M); returns M.
 template <int G>
-__device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ q_h,
-                                                      const float* __restrict__ k_base,
-                                                      const float* __restrict__ v_base,
-                                                      int kv_stride, int hs, int pos,
-                                                      float* __restrict__ out_h, float* smem) {
+__device__ __forceinline__ float attn_fast_partial(const float* __restrict__ q_h,
+                                                   const float* __restrict__ k_base,
+                                                   const float* __restrict__ v_base,
+                                                   int kv_stride, int hs, int t_begin, int t_end,
+                                                   float* smem, float& r_out, float& L_out) {
   static_assert(G == 16 || G == 32 || G == 64, "G must be 16, 32 or 64");
   constexpr int TPI = KH_WG / G;
   float* red = smem;          // [8]
@@ -176,18 +218,17 @@ __device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ 
   const f32x4* K4 = (const f32x4*)k_base;
   const f32x4* V4 = (const f32x4*)v_base;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const int nT = pos + 1;
   const float scale = 1.0f / sqrtf((float)hs);
   const f32x4 q4 = active ? ((const f32x4*)q_h)[dl] : zero4;
 
   float m = -INFINITY, l = 0.f;
   f32x4 o = zero4;
-  for (int tb = tg; tb < nT; tb += TPI * KH_ATTN_UB) {
+  for (int tb = t_begin + tg; tb < t_end; tb += TPI * KH_ATTN_UB) {
     f32x4 kv[KH_ATTN_UB], vv[KH_ATTN_UB];
 #pragma unroll
     for (int u = 0; u < KH_ATTN_UB; ++u) {
       const int t = tb + u * TPI;
-      const int tt = t < nT ? t : nT - 1;
+      const int tt = t < t_end ? t : t_end - 1;
       kv[u] = active ? K4[(size_t)tt * stride4 + dl] : zero4;
       vv[u] = active ? V4[(size_t)tt * stride4 + dl] : zero4;
     }
@@ -195,7 +236,7 @@ __device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ 
     for (int u = 0; u < KH_ATTN_UB; ++u) {
       const int t = tb + u * TPI;
       const float s = group_sum<G>(fma4(q4, kv[u], 0.f)) * scale;  // all lanes: DPP, no branch
-      if (t < nT) {
+      if (t < t_end) {
         const float m_new = fmaxf(m, s);
         const float alpha = expf(m - m_new);  // exp(-inf) = 0 on the first timestep
         const float p = expf(s - m_new);
@@ -222,13 +263,82 @@ __device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ 
   if (lane < G && active) ((f32x4*)(opart + wave * hs))[dl] = o;
   if (lane == 0) lpart[wave] = l;
   __syncthreads();
+  float r = 0.f, L = 0.f;
   if (tid < hs) {
-    float r = 0.f, L = 0.f;
 #pragma unroll
     for (int w = 0; w < KH_WAVES_PER_WG; ++w) {
       r += opart[w * hs + tid];
       L += lpart[w];
     }
-    out_h[tid] = r / L;
   }
+  r_out = r;
+  L_out = L;
+  return M;
+}
+
+// One workgroup = (head h, split s) of a grid of heads*NS workgroups.  ws may be null iff NS==1.
+template <int G>
+__device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ q_h,
+                                                      const float* __restrict__ k_base,
+                                                      const float* __restrict__ v_base,
+                                                      int kv_stride, int hs, int pos,
+                                                      float* __restrict__ out_h, float* smem,
+                                                      int h, int s, int NS, AttnSplitWs ws) {
+  const int tid = threadIdx.x;
+  const int nT = pos + 1;
+  int TS = (nT + NS - 1) / NS;
+  TS = (TS + 63) & ~63;
+  if (TS < KH_ATTN_MIN_TS) TS = KH_ATTN_MIN_TS;
+  const int nact = (nT + TS - 1) / TS;  // uniform over the grid
+  if (s >= nact) return;
+  const int t_begin = s * TS;
+  const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
+  float r, L;
+  const float M = attn_fast_partial<G>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end, smem,
+                                       r, L);
+  if (nact == 1) {
+    if (tid < hs) out_h[tid] = r / L;
+    return;
+  }
+  // ---- publish this split's partial, take a ticket ---------------------------------------
+  const size_t slot = (size_t)h * NS + s;
+  if (tid < hs) ws.o[slot * hs + tid] = r;
+  if (tid == 0) {
+    ws.ml[slot * 2] = M;
+    ws.ml[slot * 2 + 1] = L;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+  __syncthreads();
+  int* flag = (int*)smem;  // red[] is free again after the barriers inside attn_fast_partial
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wait the compiler may drop (guide G16)
+    flag[0] = __hip_atomic_fetch_add(&ws.cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (flag[0] != nact - 1) return;  // not the last arriver
+  // ---- last arriver: merge every split's partial ----------------------------------------------
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  if (tid < hs) {
+    // agent-scope relaxed atomic loads: vector path to L2, never the scalar cache
+    float Mx = -INFINITY;
+    for (int k = 0; k < nact; ++k)
+      Mx = fmaxf(Mx, __hip_atomic_load(&ws.ml[((size_t)h * NS + k) * 2], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT));
+    float num = 0.f, den = 0.f;
+    for (int k = 0; k < nact; ++k) {
+      const size_t sl = (size_t)h * NS + k;
+      const float Mk = __hip_atomic_load(&ws.ml[sl * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float Lk =
+          __hip_atomic_load(&ws.ml[sl * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float ok =
+          __hip_atomic_load(&ws.o[sl * hs + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float f = expf(Mk - Mx);
+      num = __builtin_fmaf(ok, f, num);
+      den = __builtin_fmaf(Lk, f, den);
+    }
+    out_h[tid] = num / den;
+  }
+  if (tid == 0) __hip_atomic_store(&ws.cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

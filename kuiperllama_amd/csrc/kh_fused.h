@@ -142,16 +142,25 @@ struct KhAttnArgs {
   float* out;              // [dim]
   const int32_t* d_pos;
   int kv_dim, kv_mul, head_size;
+  int kv_heads, nsplit;    // grid = kv_heads * kv_mul * nsplit workgroups
+  void* ws;                // attn_ws_bytes(heads, head_size, nsplit), tickets zeroed
 };
 template <int G>
 __global__ __launch_bounds__(KH_WG) void k_attn(const KhAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int pos = *a.d_pos;
-  const int h = blockIdx.x;
-  const size_t head_off = (size_t)(h / a.kv_mul) * a.head_size;
+  // block -> (kv group g, head-in-group j, split s): blocks are placed on XCD b % 8, so with
+  // g = b % kv_heads the kv_mul heads that share K/V rows share an XCD's L2 (kv_heads % 8 == 0)
+  const int b = blockIdx.x;
+  const int g = b % a.kv_heads;
+  const int j = (b / a.kv_heads) % a.kv_mul;
+  const int s = b / (a.kv_heads * a.kv_mul);
+  const int h = g * a.kv_mul + j;
+  const size_t head_off = (size_t)g * a.head_size;
   attn_head_decode_fast<G>(a.q + (size_t)h * a.head_size, a.kcache_layer + head_off,
                            a.vcache_layer + head_off, a.kv_dim, a.head_size, pos,
-                           a.out + (size_t)h * a.head_size, (float*)smem_raw);
+                           a.out + (size_t)h * a.head_size, (float*)smem_raw, h, s, a.nsplit,
+                           attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.nsplit));
 }
 
 // head_size <= 32 (tiny test models): the generic LDS-score core of the op-level kernel

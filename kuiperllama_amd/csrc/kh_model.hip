@@ -50,6 +50,8 @@ struct kh_model {
   float* part_val = nullptr;
   int32_t* part_idx = nullptr;
   int nparts = 0;
+  void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
+  int attn_ns = 1;
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
@@ -221,15 +223,19 @@ void launch_attn(kh_model* m, int l) {
   a.kv_dim = c.kv_dim;
   a.kv_mul = c.kv_mul;
   a.head_size = c.head_size;
+  a.kv_heads = c.kv_head_num;
+  a.nsplit = m->attn_ns;
+  a.ws = m->attn_ws;
   int G = 1;
   while (G < c.head_size / 4) G <<= 1;
   const size_t lds = attn_fast_lds_bytes(c.head_size);
+  const dim3 grid(c.head_num * m->attn_ns);
   if (G <= 16 && c.head_size > 32)
-    hipLaunchKernelGGL(k_attn<16>, dim3(c.head_num), dim3(KH_WG), lds, m->stream, a);
+    hipLaunchKernelGGL(k_attn<16>, grid, dim3(KH_WG), lds, m->stream, a);
   else if (G == 32)
-    hipLaunchKernelGGL(k_attn<32>, dim3(c.head_num), dim3(KH_WG), lds, m->stream, a);
+    hipLaunchKernelGGL(k_attn<32>, grid, dim3(KH_WG), lds, m->stream, a);
   else if (G == 64)
-    hipLaunchKernelGGL(k_attn<64>, dim3(c.head_num), dim3(KH_WG), lds, m->stream, a);
+    hipLaunchKernelGGL(k_attn<64>, grid, dim3(KH_WG), lds, m->stream, a);
   else  // head_size <= 32: generic LDS-score kernel (tiny test models)
     hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(KH_WG),
                        attn_lds_bytes(c.head_size), m->stream, a);
@@ -596,6 +602,11 @@ int finish_create(kh_model* m) {
   m->sh_w2 = pick_shape(c.is_quant, c.dim / 2, c.hidden_dim, 4, "KH_SHAPE_W2");
   m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS");
   m->nparts = m->sh_cls.grid;
+  m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
+  if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ns)) {
+    KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
+    KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));
+  }
   KH_ALLOC(m->part_val, (size_t)m->nparts);
   KH_ALLOC(m->part_idx, (size_t)m->nparts);
 #undef KH_ALLOC
@@ -684,7 +695,7 @@ extern "C" void kh_model_destroy(kh_model* m) {
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
                   m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
                   m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
-                  m->d_forced, m->d_words};
+                  m->d_forced, m->d_words, m->attn_ws};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (m->owns_arena && m->arena) (void)hipFree(m->arena);

@@ -427,6 +427,52 @@ __global__ __launch_bounds__(KH_WG) void k_mha(const int32_t* __restrict__ d_pos
                    (float*)smem_raw);
 }
 
+template <int G>
+__global__ __launch_bounds__(KH_WG) void k_mha_fast(const int32_t* __restrict__ d_pos, int pos_val,
+                                                    int layer_index, int seq_len, int kv_dim,
+                                                    int kv_mul, int head_size, int head_num,
+                                                    int nsplit, void* ws,
+                                                    float* __restrict__ mha_out,
+                                                    const float* __restrict__ q,
+                                                    const float* __restrict__ kcache,
+                                                    const float* __restrict__ vcache) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int pos = d_pos ? *d_pos : pos_val;
+  const int kv_heads = head_num / kv_mul;
+  const int b = blockIdx.x;
+  const int g = b % kv_heads;
+  const int j = (b / kv_heads) % kv_mul;
+  const int s = b / head_num;
+  const int h = g * kv_mul + j;
+  const size_t layer_off = (size_t)layer_index * (size_t)seq_len * (size_t)kv_dim;
+  const size_t head_off = (size_t)g * head_size;
+  attn_head_decode_fast<G>(q + (size_t)h * head_size, kcache + layer_off + head_off,
+                           vcache + layer_off + head_off, kv_dim, head_size, pos,
+                           mha_out + (size_t)h * head_size, (float*)smem_raw, h, s, nsplit,
+                           attn_ws_carve(ws, head_num, head_size, nsplit));
+}
+
+static int launch_mha_fast(const int32_t* d_pos, int32_t pos, int32_t head_num,
+                           int32_t layer_index, int32_t seq_len, int32_t kv_dim, int32_t kv_mul,
+                           int32_t head_size, float* mha_out, const float* q, const float* kcache,
+                           const float* vcache, int nsplit, void* ws, hipStream_t s) {
+  int G = 1;
+  while (G < head_size / 4) G <<= 1;
+  const size_t lds = attn_fast_lds_bytes(head_size);
+#define KH_MHA_FAST(GG)                                                                        \
+  hipLaunchKernelGGL(k_mha_fast<GG>, dim3(head_num * nsplit), dim3(KH_WG), lds, s, d_pos, pos, \
+                     layer_index, seq_len, kv_dim, kv_mul, head_size, head_num, nsplit, ws,    \
+                     mha_out, q, kcache, vcache)
+  if (G <= 16)
+    KH_MHA_FAST(16);
+  else if (G == 32)
+    KH_MHA_FAST(32);
+  else
+    KH_MHA_FAST(64);
+#undef KH_MHA_FAST
+  return kh_launch_status();
+}
+
 extern "C" int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
                           int32_t layer_index, int32_t seq_len, int32_t kv_dim, int32_t kv_mul,
                           int32_t head_size, float* mha_out, const float* q, float* score,
@@ -437,10 +483,43 @@ extern "C" int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
       !kh_aligned16(q) || !kh_aligned16(kcache) || !kh_aligned16(vcache) ||
       !kh_aligned16(mha_out))
     return KH_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(k_mha, dim3(head_num), dim3(KH_WG), attn_lds_bytes(head_size),
-                     (hipStream_t)stream, d_pos, pos, layer_index, seq_len, kv_dim, kv_mul,
-                     head_size, mha_out, q, score, kcache, vcache);
+  hipStream_t s = (hipStream_t)stream;
+  if (!score && head_size > 32 && head_num % kv_mul == 0)
+    // no score tensor requested: the fused decode path's one-round-trip kernel (kh_attn.h),
+    // one workgroup per head (kh_mha_decode_f32 adds the long-context time split)
+    return launch_mha_fast(d_pos, pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
+                           mha_out, q, kcache, vcache, 1, nullptr, s);
+  hipLaunchKernelGGL(k_mha, dim3(head_num), dim3(KH_WG), attn_lds_bytes(head_size), s, d_pos,
+                     pos, layer_index, seq_len, kv_dim, kv_mul, head_size, mha_out, q, score,
+                     kcache, vcache);
   return kh_launch_status();
+}
+
+// Decode attention with the long-context time split (the kernel the fused step launches).
+extern "C" int64_t kh_mha_decode_workspace_bytes(int32_t head_num, int32_t head_size,
+                                                 int32_t seq_len) {
+  if (head_num <= 0 || head_size <= 0 || seq_len <= 0) return KH_ERR_INVALID_ARG;
+  const int ns = head_size > 32 ? attn_num_splits(seq_len) : 1;
+  return (int64_t)attn_ws_bytes(head_num, head_size, ns);
+}
+extern "C" int kh_mha_decode_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
+                                 int32_t layer_index, int32_t seq_len, int32_t kv_dim,
+                                 int32_t kv_mul, int32_t head_size, float* mha_out, const float* q,
+                                 const float* kcache, const float* vcache, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  const int ns = head_size > 32 ? attn_num_splits(seq_len) : 1;
+  if (head_size <= 32 || kv_mul <= 0 || head_num % kv_mul)
+    return kh_mha_f32(d_pos, pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
+                      mha_out, q, nullptr, kcache, vcache, stream);
+  if (!mha_out || !q || !kcache || !vcache || head_num <= 0 || layer_index < 0 || seq_len <= 0 ||
+      kv_dim <= 0 || head_size % 4 || head_size > 256 || kv_dim % 4 ||
+      (!d_pos && (pos < 0 || pos >= seq_len)) || !kh_aligned16(q) || !kh_aligned16(kcache) ||
+      !kh_aligned16(vcache) || !kh_aligned16(mha_out) ||
+      (ns > 1 && (!workspace || workspace_bytes < (int64_t)attn_ws_bytes(head_num, head_size, ns) ||
+                  !kh_aligned16(workspace))))
+    return KH_ERR_INVALID_ARG;
+  return launch_mha_fast(d_pos, pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
+                         mha_out, q, kcache, vcache, ns, workspace, (hipStream_t)stream);
 }
 
 // =============================================================================================

@@ -99,8 +99,28 @@ def mha(pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size, mha_out,
     d_pos, ipos = (None, int(pos)) if not torch.is_tensor(pos) else (_p(pos, torch.int32), 0)
     _ffi.check(_ffi.lib().kh_mha_f32(d_pos, ipos, head_num, layer_index, seq_len, kv_dim, kv_mul,
                                      head_size, _p(mha_out, torch.float32), _p(q, torch.float32),
-                                     _p(score, torch.float32), _p(kcache, torch.float32),
+                                     _p(score, torch.float32) if score is not None else None,
+                                     _p(kcache, torch.float32),
                                      _p(vcache, torch.float32), _stream()), "kh_mha_f32")
+    return mha_out
+
+
+def mha_decode_workspace(head_num: int, head_size: int, seq_len: int, device):
+    """Zeroed workspace tensor for mha_decode (None when no time split is needed)."""
+    n = int(_ffi.lib().kh_mha_decode_workspace_bytes(head_num, head_size, seq_len))
+    if n < 0:
+        _ffi.check(n, "kh_mha_decode_workspace_bytes")
+    return torch.zeros(n, dtype=torch.uint8, device=device) if n else None
+
+
+def mha_decode(pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size, mha_out, q, kcache,
+               vcache, workspace):
+    d_pos, ipos = (None, int(pos)) if not torch.is_tensor(pos) else (_p(pos, torch.int32), 0)
+    _ffi.check(_ffi.lib().kh_mha_decode_f32(
+        d_pos, ipos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
+        _p(mha_out, torch.float32), _p(q, torch.float32), _p(kcache, torch.float32),
+        _p(vcache, torch.float32), _p(workspace) if workspace is not None else None,
+        workspace.numel() if workspace is not None else 0, _stream()), "kh_mha_decode_f32")
     return mha_out
 
 

@@ -25,3 +25,35 @@ def test_adapter_compiles_and_links_without_gpu():
 def test_adapter_reference_op_tests_on_gpu(gpu):
     r = _run()
     assert r.returncode == 0 and "OK adapter tests passed" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["graph", "unfused"])
+def test_demo_cli_matches_oracle(gpu, oracle, tmp_path, mode):
+    """tools/kuiper_demo.cpp (the reference's demo/main.cpp over the C-ABI, .bin read from a
+    FILE with mmap like model.cpp:41-123) generates the oracle's token ids."""
+    from conftest import load_golden
+    spec, img, toks, _ = load_golden("hf_llama_half")
+    path = tmp_path / "m.bin"
+    img.tofile(path)
+    prompt = [int(t) for t in toks[:3]]
+    want = oracle.OracleModel.from_spec(img, spec).generate(prompt, 24)
+    exe = build.build_demo()
+    r = subprocess.run([exe, str(path), "--rope", "half", "--theta", str(spec.rope_theta), "--eps",
+                        str(spec.rms_eps), "--steps", "24", "--prompt",
+                        ",".join(map(str, prompt)), "--exec", mode],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    ids = [int(t) for t in lines[1].split()]
+    assert ids == want
+    assert lines[2].startswith("steps/s:")
+
+
+def test_demo_cli_builds_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = build.build_demo()
+    r = subprocess.run([exe, "/nonexistent.bin"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "init failed" in r.stderr

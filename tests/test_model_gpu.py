@@ -127,6 +127,23 @@ def test_token_parity_128_steps(gpu, oracle, spec):
     m.close()
 
 
+def test_long_generate_crosses_attention_splits(gpu, oracle):
+    """cache_len 4096 -> the attention grid carries 4 splits per head; a 700-step greedy run
+    crosses the 1->2 (pos 256) and 2->3 (pos 512) split transitions inside the hipGraph."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.ModelSpec(256, 512, 2, 4, 2, 512, 4096, True, binfmt.FAMILY_LLAMA, False, 64,
+                            binfmt.ROPE_HALF, 500000.0, 1e-5, "long-ctx")
+    img_d, img_h = _synth(spec, 99, gpu)
+    steps = 700
+    want = oracle.OracleModel.from_spec(img_h, spec, cache_len=1024).generate([1, 2, 3], steps)
+    m = KuiperModel.from_device_image(img_d, spec)
+    got, _ = m.generate([1, 2, 3], steps, exec="graph")
+    assert got == want, next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    got2, _ = m.generate([1, 2, 3], steps, exec="fused")
+    assert got2 == want
+    m.close()
+
+
 def test_loader_entry_points_agree(gpu):
     from kuiperllama_amd.model import KuiperModel
     spec, img, toks, ref = load_golden("ref_llama_mha_untied")

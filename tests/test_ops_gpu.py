@@ -264,6 +264,10 @@ def test_mha_vs_oracle(gpu, oracle, heads, kv_heads, hs, seq, layers):
             # probabilities are left in the score tensor like the reference
             np.testing.assert_allclose(host(score)[:, : pos + 1], so[:, : pos + 1], rtol=0,
                                        atol=2e-6)
+            # score=None: the fused decode path's kernel (no score tensor), same answer
+            out2 = torch.full((dim,), float("nan"), device=gpu)
+            ops.mha(pos, heads, layer, seq, kv_dim, kv_mul, hs, out2, qd, None, kcd, vcd)
+            np.testing.assert_allclose(host(out2), oo, rtol=0, atol=2e-5)
 
 
 def test_mha_long_context_multi_chunk(gpu, oracle):
@@ -285,6 +289,41 @@ def test_mha_long_context_multi_chunk(gpu, oracle):
         oo, so = oracle.mha(pos, heads, 0, seq, kv_dim, kv_mul, hs, q, kc, vc, acc=oracle.ACC_F64)
         np.testing.assert_allclose(host(out), oo, rtol=0, atol=3e-5)
         np.testing.assert_allclose(host(score)[:, : pos + 1], so[:, : pos + 1], rtol=0, atol=3e-6)
+        # the decode path's kernel (running max per lane group, merged once at the end) on the
+        # same spiked input
+        out2 = torch.full((dim,), float("nan"), device=gpu)
+        ops.mha(torch.tensor([pos], dtype=torch.int32, device=gpu), heads, 0, seq, kv_dim, kv_mul,
+                hs, out2, dev(q, gpu), None, dev(kc, gpu), dev(vc, gpu))
+        np.testing.assert_allclose(host(out2), oo, rtol=0, atol=3e-5)
+
+
+def test_mha_decode_time_split(gpu, oracle):
+    """kh_mha_decode_f32 = the kernel the fused step launches: NS workgroups per head, the last
+    arriver merges the partial (max, sum, o) triples.  Checks the 1 -> 2 -> 3... split
+    transitions (pos 255/256, 511/512, ...), a spiked key, workspace re-arming across calls and
+    layers, and GQA (kv_mul 4) / MHA (kv_mul 1) head mappings."""
+    from kuiperllama_amd import ops
+    for heads, kv_heads, hs, seq in ((8, 2, 64, 6000), (4, 4, 128, 3000)):
+        rng = np.random.default_rng(heads + seq)
+        kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+        kc = rng.standard_normal((2, seq, kv_dim)).astype(np.float32)
+        vc = rng.standard_normal((2, seq, kv_dim)).astype(np.float32)
+        q = rng.standard_normal(dim).astype(np.float32)
+        kc[1, 1500, :hs] = 3.0 * q[:hs]
+        ws = ops.mha_decode_workspace(heads, hs, seq, gpu)
+        assert ws is not None and ws.numel() > 0
+        kcd, vcd, qd = dev(kc, gpu), dev(vc, gpu), dev(q, gpu)
+        for layer in (0, 1):
+            for pos in (0, 100, 255, 256, 257, 511, 512, 1023, 1024, 1499, 1500, 2047, 2999,
+                        seq - 1):
+                out = torch.full((dim,), float("nan"), device=gpu)
+                ops.mha_decode(torch.tensor([pos], dtype=torch.int32, device=gpu), heads, layer,
+                               seq, kv_dim, kv_mul, hs, out, qd, kcd, vcd, ws)
+                oo, _ = oracle.mha(pos, heads, layer, seq, kv_dim, kv_mul, hs, q, kc, vc,
+                                   acc=oracle.ACC_F64)
+                np.testing.assert_allclose(host(out), oo, rtol=0, atol=3e-5,
+                                           err_msg=f"heads {heads} layer {layer} pos {pos}")
+        assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
 
 
 # ---------------------------------------------------------------- CPU-only helpers of the reference

@@ -1,0 +1,100 @@
+// kuiper_demo — command-line twin of the reference's demo/main.cpp / demo/main_qwen.cpp on top of
+// the C-ABI (include/kuiper_hip.h).  The reference hard-codes tokenizer type, quantisation,
+// device and prompt in the source; here they are flags.  Tokenisation is out of
+// scope, so the prompt is given as token ids and ids are printed.
+//
+//   kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]
+//               [--theta 10000] [--eps 1e-5] [--steps 128] [--prompt 1,263]
+//               [--exec graph|fused|unfused] [--max-seq-len N] [--device 0]
+//
+// Prints the generated ids and "steps/s" like demo/main.cpp:70-72.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kuiper_hip.h"
+
+static void usage() {
+  std::fprintf(stderr,
+               "usage: kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]\n"
+               "       [--theta F] [--eps F] [--steps N] [--prompt id,id,...] [--exec graph|fused|unfused]\n"
+               "       [--max-seq-len N] [--device D]\n");
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    usage();
+    return 2;
+  }
+  const char* path = argv[1];
+  kh_model_opts o{KH_FAMILY_LLAMA, 0, KH_ROPE_INTERLEAVED, 10000.f, 1e-5f, 0, 0, 0};
+  int steps = 128, exec = KH_EXEC_GRAPH;
+  std::vector<int32_t> prompt{1, 263};  // BOS + "a": the reference demo's prompt (main.cpp:64)
+  for (int i = 2; i < argc; ++i) {
+    std::string a = argv[i];
+    auto next = [&]() -> const char* {
+      if (i + 1 >= argc) {
+        usage();
+        std::exit(2);
+      }
+      return argv[++i];
+    };
+    if (a == "--family") o.family = std::string(next()) == "qwen2" ? KH_FAMILY_QWEN2 : KH_FAMILY_LLAMA;
+    else if (a == "--quant") o.is_quant = 1;
+    else if (a == "--rope") o.rope_mode = std::string(next()) == "half" ? KH_ROPE_HALF : KH_ROPE_INTERLEAVED;
+    else if (a == "--theta") o.rope_theta = (float)std::atof(next());
+    else if (a == "--eps") o.rms_eps = (float)std::atof(next());
+    else if (a == "--steps") steps = std::atoi(next());
+    else if (a == "--max-seq-len") o.max_seq_len = std::atoi(next());
+    else if (a == "--device") o.device = std::atoi(next());
+    else if (a == "--exec") {
+      std::string e = next();
+      exec = e == "unfused" ? KH_EXEC_UNFUSED : (e == "fused" ? KH_EXEC_FUSED : KH_EXEC_GRAPH);
+    } else if (a == "--prompt") {
+      prompt.clear();
+      std::string s = next();
+      size_t p = 0;
+      while (p < s.size()) {
+        size_t q = s.find(',', p);
+        if (q == std::string::npos) q = s.size();
+        prompt.push_back(std::atoi(s.substr(p, q - p).c_str()));
+        p = q + 1;
+      }
+    } else {
+      usage();
+      return 2;
+    }
+  }
+  kh_model* m = nullptr;
+  int rc = kh_model_create_from_file(path, &o, &m);
+  if (rc != KH_OK) {
+    std::fprintf(stderr, "The model init failed: %d (%s)\n", rc, kh_error_string(rc));
+    return 1;
+  }
+  kh_config c;
+  kh_model_get_config(m, &c);
+  std::fprintf(stderr, "dim %d hidden %d layers %d heads %d kv_heads %d vocab %d seq_len %d%s\n", c.dim,
+               c.hidden_dim, c.layer_num, c.head_num, c.kv_head_num, c.vocab_size, c.seq_len,
+               c.is_quant ? " int8" : "");
+  std::vector<int32_t> words((size_t)steps);
+  int32_t n = 0;
+  float gpu_ms = 0.f;
+  std::printf("Generating...\n");
+  const auto t0 = std::chrono::steady_clock::now();  // timer excludes init (main.cpp:66)
+  rc = kh_model_generate(m, prompt.data(), (int32_t)prompt.size(), steps, exec, words.data(), &n, &gpu_ms);
+  const auto t1 = std::chrono::steady_clock::now();
+  if (rc != KH_OK) {
+    std::fprintf(stderr, "generate failed: %d (%s)\n", rc, kh_error_string(rc));
+    kh_model_destroy(m);
+    return 1;
+  }
+  for (int i = 0; i < n; ++i) std::printf("%d ", words[i]);
+  const double dur = std::chrono::duration<double>(t1 - t0).count();
+  std::printf("\nsteps/s:%lf\n", (double)n / dur);
+  std::fprintf(stderr, "(device time of the step loop: %.3f ms)\n", gpu_ms);
+  kh_model_destroy(m);
+  return 0;
+}
