@@ -165,6 +165,8 @@ int kh_model_create_from_device_weights(const int32_t* h_header, const void* d_w
 void kh_model_destroy(kh_model* m);
 int kh_model_get_config(const kh_model* m, kh_config* out);
 void* kh_model_stream(kh_model* m); /* the model's hipStream_t */
+/* milliseconds the host-image -> HBM upload took (0 for device-resident weights) */
+float kh_model_get_load_ms(const kh_model* m);
 
 enum {
   KH_EXEC_GRAPH = 0,   /* fused kernels, whole step replayed as one hipGraph */

@@ -21,7 +21,7 @@ EXPORTS = [
     "kh_argmax_f32_host", "kh_softmax_f32", "kh_scale_f32", "kh_scale_sum_f32",
     "kh_model_create_from_file", "kh_model_create_from_host_image",
     "kh_model_create_from_device_weights", "kh_model_destroy", "kh_model_get_config",
-    "kh_model_stream", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
+    "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
     "kh_model_generate", "kh_model_profile_step", "kh_kclass_name",
 ]
 
@@ -100,6 +100,8 @@ def lib() -> C.CDLL:
     L.kh_model_get_config.argtypes = [_vp, C.POINTER(Config)]
     L.kh_model_stream.argtypes = [_vp]
     L.kh_model_stream.restype = _vp
+    L.kh_model_get_load_ms.argtypes = [_vp]
+    L.kh_model_get_load_ms.restype = _f32
     L.kh_model_predict.argtypes = [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_model_get_logits.argtypes = [_vp, _vp]
     L.kh_model_get_kv.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]

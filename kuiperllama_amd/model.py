@@ -139,5 +139,10 @@ class KuiperModel:
                 for i, n in enumerate(names)}
 
     @property
+    def load_ms(self) -> float:
+        """Host image -> HBM upload time of the loader (pinned double-buffered chunks)."""
+        return float(_ffi.lib().kh_model_get_load_ms(self._h))
+
+    @property
     def stream(self) -> int:
         return int(_ffi.lib().kh_model_stream(self._h) or 0)

@@ -165,6 +165,25 @@ def test_loader_entry_points_agree(gpu):
     np.testing.assert_allclose(outs[0], ref[3], rtol=0, atol=LOGIT_ATOL_F32)
 
 
+def test_chunked_pinned_upload_is_byte_exact(gpu):
+    """Images larger than one 64 MiB staging chunk go through the double-buffered pinned
+    uploader (kh_model.hip::upload_chunked); the arena must equal a direct device image."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.ModelSpec(512, 1408, 8, 8, 8, 32000, 128, True, binfmt.FAMILY_LLAMA, False, 64,
+                            binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "upload-168MB")
+    img_d, img_h = _synth(spec, 5, gpu)
+    assert img_h.size > 2.5 * (64 << 20)  # 3 chunks, last one partial
+    a = KuiperModel.from_host_image(img_h, spec)
+    b = KuiperModel.from_device_image(img_d, spec)
+    assert a.load_ms > 0 and b.load_ms == 0
+    for t, tok in enumerate([1, 263, 17, 4000]):
+        a.predict(tok, t)
+        b.predict(tok, t)
+    assert np.array_equal(a.logits(), b.logits())
+    a.close()
+    b.close()
+
+
 def test_max_seq_len_caps_cache(gpu):
     from kuiperllama_amd.model import KuiperModel
     from kuiperllama_amd import _ffi

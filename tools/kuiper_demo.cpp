@@ -79,6 +79,8 @@ int main(int argc, char** argv) {
   std::fprintf(stderr, "dim %d hidden %d layers %d heads %d kv_heads %d vocab %d seq_len %d%s\n", c.dim,
                c.hidden_dim, c.layer_num, c.head_num, c.kv_head_num, c.vocab_size, c.seq_len,
                c.is_quant ? " int8" : "");
+  std::fprintf(stderr, "weights: %.2f GB uploaded in %.1f ms (%.1f GB/s)\n", c.weight_bytes / 1e9,
+               kh_model_get_load_ms(m), c.weight_bytes / 1e6 / (kh_model_get_load_ms(m) + 1e-9));
   std::vector<int32_t> words((size_t)steps);
   int32_t n = 0;
   float gpu_ms = 0.f;
