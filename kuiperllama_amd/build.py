@@ -46,6 +46,10 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
+               # no implicit FMA contraction: results must not depend on which kernel a stage is
+               # inlined into (merged vs stand-alone launches are compared bit for bit) and the
+               # CPU oracle is built the same way; explicit __builtin_fmaf calls stay FMAs
+               "-ffp-contract=off",
                "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -182,6 +182,17 @@ static inline size_t attn_ws_bytes(int heads, int head_size, int ns) {
                  : (size_t)heads * sizeof(int) + (size_t)heads * ns * (2 + head_size) * sizeof(float);
 }
 
+// number of splits that own timesteps at position `pos` (uniform over the grid)
+__host__ __device__ static inline int attn_split_len(int nT, int NS) {
+  int TS = (nT + NS - 1) / NS;
+  TS = (TS + 63) & ~63;
+  return TS < KH_ATTN_MIN_TS ? KH_ATTN_MIN_TS : TS;
+}
+__host__ __device__ static inline int attn_active_splits(int pos, int NS) {
+  const int TS = attn_split_len(pos + 1, NS);
+  return (pos + 1 + TS - 1) / TS;
+}
+
 struct AttnSplitWs {
   int* cnt;        // [heads]   arrival tickets, zero between launches
   float* ml;       // [heads, NS, 2]
@@ -199,12 +210,19 @@ __host__ __device__ static inline AttnSplitWs attn_ws_carve(void* ws, int heads,
 
 // Attention of head h over timesteps [t_begin, t_end): leaves, for threads tid < hs, the
 // unnormalised output r = sum_t exp(s_t - M) v_t[tid] and L = sum_t exp(s_t - M); returns M.
-template <int G>
-__device__ __forceinline__ float attn_fast_partial(const float* __restrict__ q_h,
-                                                   const float* __restrict__ k_base,
-                                                   const float* __restrict__ v_base,
-                                                   int kv_stride, int hs, int t_begin, int t_end,
-                                                   float* smem, float& r_out, float& L_out) {
+// SC1: q and cache row `fresh_t` were written earlier in the SAME launch with sc1 stores by other
+// workgroups (merged qkv|attention launch): read those with sc1 loads; older rows are plain.
+// WAIT: called exactly once by every thread (it may contain a barrier) after the plain loads of
+// the first batch are in flight and before anything produced by this launch is read.
+struct AttnNoWait {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int G, bool SC1, class WaitFn>
+__device__ __forceinline__ float attn_fast_partial(const float* q_h, const float* k_base,
+                                                   const float* v_base, int kv_stride, int hs,
+                                                   int t_begin, int t_end, int fresh_t,
+                                                   float* smem, float& r_out, float& L_out,
+                                                   WaitFn&& WAIT) {
   static_assert(G == 16 || G == 32 || G == 64, "G must be 16, 32 or 64");
   constexpr int TPI = KH_WG / G;
   float* red = smem;          // [8]
@@ -219,18 +237,36 @@ __device__ __forceinline__ float attn_fast_partial(const float* __restrict__ q_h
   const f32x4* V4 = (const f32x4*)v_base;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const float scale = 1.0f / sqrtf((float)hs);
-  const f32x4 q4 = active ? ((const f32x4*)q_h)[dl] : zero4;
-
+  f32x4 q4 = zero4;
   float m = -INFINITY, l = 0.f;
   f32x4 o = zero4;
-  for (int tb = t_begin + tg; tb < t_end; tb += TPI * KH_ATTN_UB) {
+  bool first = true;  // every thread runs the body at least once: WAIT may hold a barrier
+  for (int tb = t_begin + tg; first || tb < t_end; tb += TPI * KH_ATTN_UB) {
     f32x4 kv[KH_ATTN_UB], vv[KH_ATTN_UB];
 #pragma unroll
-    for (int u = 0; u < KH_ATTN_UB; ++u) {
+    for (int u = 0; u < KH_ATTN_UB; ++u) {  // rows of earlier steps: plain loads, issued first
       const int t = tb + u * TPI;
       const int tt = t < t_end ? t : t_end - 1;
-      kv[u] = active ? K4[(size_t)tt * stride4 + dl] : zero4;
-      vv[u] = active ? V4[(size_t)tt * stride4 + dl] : zero4;
+      if (!(SC1 && tt == fresh_t)) {
+        kv[u] = active ? K4[(size_t)tt * stride4 + dl] : zero4;
+        vv[u] = active ? V4[(size_t)tt * stride4 + dl] : zero4;
+      }
+    }
+    if (first) {
+      WAIT();
+      q4 = active ? (SC1 ? ld4_sc1((const f32x4*)q_h + dl) : ((const f32x4*)q_h)[dl]) : zero4;
+      first = false;
+    }
+    if (SC1) {
+#pragma unroll
+      for (int u = 0; u < KH_ATTN_UB; ++u) {  // the row this launch produced: sc1 loads
+        const int t = tb + u * TPI;
+        const int tt = t < t_end ? t : t_end - 1;
+        if (tt == fresh_t) {
+          kv[u] = active ? ld4_sc1(K4 + (size_t)tt * stride4 + dl) : zero4;
+          vv[u] = active ? ld4_sc1(V4 + (size_t)tt * stride4 + dl) : zero4;
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < KH_ATTN_UB; ++u) {
@@ -277,28 +313,32 @@ __device__ __forceinline__ float attn_fast_partial(const float* __restrict__ q_h
 }
 
 // One workgroup = (head h, split s) of a grid of heads*NS workgroups.  ws may be null iff NS==1.
-template <int G>
-__device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ q_h,
-                                                      const float* __restrict__ k_base,
-                                                      const float* __restrict__ v_base,
-                                                      int kv_stride, int hs, int pos,
-                                                      float* __restrict__ out_h, float* smem,
-                                                      int h, int s, int NS, AttnSplitWs ws) {
+// Returns true in the workgroup that wrote the head's final output.  SC1: see attn_fast_partial;
+// the output then also leaves with sc1 stores (consumed by the wo stage of the same launch).
+template <int G, bool SC1 = false, class WaitFn = AttnNoWait>
+__device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const float* k_base,
+                                                      const float* v_base, int kv_stride, int hs,
+                                                      int pos, float* out_h, float* smem, int h,
+                                                      int s, int NS, AttnSplitWs ws,
+                                                      WaitFn&& WAIT = WaitFn()) {
   const int tid = threadIdx.x;
   const int nT = pos + 1;
-  int TS = (nT + NS - 1) / NS;
-  TS = (TS + 63) & ~63;
-  if (TS < KH_ATTN_MIN_TS) TS = KH_ATTN_MIN_TS;
+  const int TS = attn_split_len(nT, NS);
   const int nact = (nT + TS - 1) / TS;  // uniform over the grid
-  if (s >= nact) return;
+  if (s >= nact) return false;
   const int t_begin = s * TS;
   const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
   float r, L;
-  const float M = attn_fast_partial<G>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end, smem,
-                                       r, L);
+  const float M = attn_fast_partial<G, SC1>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end,
+                                            pos, smem, r, L, WAIT);
   if (nact == 1) {
-    if (tid < hs) out_h[tid] = r / L;
-    return;
+    if (tid < hs) {
+      if (SC1)
+        st_sc1(out_h + tid, r / L);
+      else
+        out_h[tid] = r / L;
+    }
+    return true;
   }
   // ---- publish this split's partial, take a ticket ---------------------------------------
   const size_t slot = (size_t)h * NS + s;
@@ -316,7 +356,7 @@ __device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ 
     flag[0] = __hip_atomic_fetch_add(&ws.cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (flag[0] != nact - 1) return;  // not the last arriver
+  if (flag[0] != nact - 1) return false;  // not the last arriver
   // ---- last arriver: merge every split's partial ----------------------------------------------
   if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
@@ -338,7 +378,11 @@ __device__ __forceinline__ void attn_head_decode_fast(const float* __restrict__ 
       num = __builtin_fmaf(ok, f, num);
       den = __builtin_fmaf(Lk, f, den);
     }
-    out_h[tid] = num / den;
+    if (SC1)
+      st_sc1(out_h + tid, num / den);
+    else
+      out_h[tid] = num / den;
   }
   if (tid == 0) __hip_atomic_store(&ws.cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
 }

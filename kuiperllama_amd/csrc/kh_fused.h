@@ -38,6 +38,30 @@ static inline size_t fused_lds_bytes(bool quant, int M) {
   return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 16 + 32;
 }
 
+// Three-way select on VALUES.  Written as `w == 0 ? a : ...` directly on named variables, the
+// conditional operator yields an lvalue, clang selects between the variables' ADDRESSES, and the
+// variables (kernel-argument pointers) are forced into scratch memory.
+template <class T>
+__device__ __forceinline__ T sel3(int w, T a, T b, T c) {
+  return w == 0 ? a : (w == 1 ? b : c);
+}
+
+// Hand-off words of one layer for the merged [qkv | attention | wo] launch (kh_merged.h);
+// zeroed by k_sample at the end of every decode step.
+// Every counter sits in its own 128-byte line (KH_SYNC_STRIDE ints apart): agent-scope polls and
+// atomics are served at the memory side, where requests to one line serialise (~88 per us,
+// guide "dequeue" row) — 512 pollers on one word turned a 15 us stage into 50 us.  The
+// attention->wo counter is additionally replicated 8x (one per XCD, picked by workgroup id).
+#define KH_SYNC_STRIDE 32
+#define KH_SYNC_REPL 8
+struct KhSync {
+  int* cnt_qkv;     // [kv_heads][STRIDE] arrivals of qkv workgroup-iterations, per KV group
+  int* cnt_attn;    // [REPL][STRIDE]     arrivals of finished attention heads (replicated)
+  int* err;         // [1]        set when a bounded wait timed out
+  int expect_qkv;   // arrivals that complete one KV group's q, k and v rows
+  int expect_attn;  // = head_num
+};
+
 // ---------------------------------------------------------------------------------------------
 struct KhQkvArgs {
   const float* x;         // residual stream [dim]
@@ -53,20 +77,38 @@ struct KhQkvArgs {
   float eps;
 };
 
-template <bool QUANT, int U, int MAXV, int SPLIT>
-__global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// MERGED: this stage shares its launch with its consumers: results leave with write-through
+// (sc1) stores and every workgroup-iteration arrives on its KV group's counter.
+template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED>
+__device__ __forceinline__ void qkv_body(const KhQkvArgs& a, char* smem_raw, int vb, int vgrid,
+                                         const KhSync& sync) {
+  // Every kernel argument used inside the lambdas is first copied into a scalar local: a
+  // lambda that captures the argument STRUCT by reference keeps the whole struct addressable
+  // and the compiler then parks it in scratch memory (seen as 168 B/lane of scratch traffic).
+  const void *wq_w = a.wq.w, *wk_w = a.wk.w, *wv_w = a.wv.w;
+  const float *wq_s = a.wq.scales, *wk_s = a.wk.scales, *wv_s = a.wv.scales;
+  const float *wq_b = a.wq.bias, *wk_b = a.wk.bias, *wv_b = a.wv.bias;
+  float* const q_out = a.q_out;
+  float* const kc = a.kcache_layer;
+  float* const vc = a.vcache_layer;
+  const float* const sin_cache = a.sin_cache;
+  const float* const cos_cache = a.cos_cache;
+  const int dim = a.dim, kv_dim = a.kv_dim, rope_mode = a.rope_mode;
+  const float eps = a.eps;
+  int* const cnt_qkv = sync.cnt_qkv;
   f32x4* xs = (f32x4*)smem_raw;
-  float* red = lds_red_ptr<QUANT>(xs, a.dim);
+  float* red = lds_red_ptr<QUANT>(xs, dim);
   const int lane = threadIdx.x & 63;
   const int hs = a.head_size, half = hs >> 1;
-  const int npq = a.dim >> 1, npk = a.kv_dim >> 1;
+  const int npq = dim >> 1, npk = kv_dim >> 1;
   const int total = npq + 2 * npk;
-  const Gemv<QUANT, U> g(a.dim, a.gshift);
-  Stager<true, QUANT, MAXV> st(a.x, a.att_norm, a.dim);
+  const int kv_mul = dim / kv_dim;
+  const Gemv<QUANT, U> g(dim, a.gshift);
+  Stager<true, QUANT, MAXV> st(a.x, a.att_norm, dim);
+  const int pos = *a.d_pos;
 
   // work item p -> (which projection, row pair, sin/cos column)
-  auto decode = [&](int p, int& which, int& r0, int& r1, int& cidx) {
+  auto decode = [&](int p, int& which, int& r0, int& r1, int& cidx) __attribute__((always_inline)) {
     int pp;
     if (p < npq) {
       which = 0;
@@ -78,7 +120,7 @@ __global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
       which = 2;
       pp = p - npq - npk;
     }
-    if (which < 2 && a.rope_mode == KH_ROPE_HALF) {
+    if (which < 2 && rope_mode == KH_ROPE_HALF) {
       // cpu/rope_kernel.cpp:18-42: pair (head*hs + j, + hs/2), cache column 2j
       const int head = pp / half, j = pp - head * half;
       r0 = head * hs + j;
@@ -91,47 +133,72 @@ __global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
       cidx = r0 % hs;
     }
   };
-  auto pair = [&](int p) {
+  auto pair = [&](int p) __attribute__((always_inline)) {
     int which, r0, r1, cidx;
     decode(p, which, r0, r1, cidx);
-    const KhLin& L = which == 0 ? a.wq : (which == 1 ? a.wk : a.wv);
-    return g.rows(L.w, r0, L.w, r1, L.scales, L.scales, a.dim);
+    const void* w = sel3(which, wq_w, wk_w, wv_w);
+    const float* sc = sel3(which, wq_s, wk_s, wv_s);
+    return g.rows(w, r0, w, r1, sc, sc, dim);
   };
-  const int pos = *a.d_pos;
   struct Aux {
     float fci, fcr, b0, b1;
   };
-  auto pre = [&](int p) {
+  auto pre = [&](int p) __attribute__((always_inline)) {
     int which, r0, r1, cidx;
     decode(p, which, r0, r1, cidx);
-    const KhLin& L = which == 0 ? a.wq : (which == 1 ? a.wk : a.wv);
+    const float* bias = sel3(which, wq_b, wk_b, wv_b);
     Aux x;
-    x.fci = a.sin_cache[(size_t)pos * hs + cidx];
-    x.fcr = a.cos_cache[(size_t)pos * hs + cidx];
-    x.b0 = L.bias ? L.bias[r0] : 0.f;
-    x.b1 = L.bias ? L.bias[r1] : 0.f;
+    x.fci = sin_cache[(size_t)pos * hs + cidx];
+    x.fcr = cos_cache[(size_t)pos * hs + cidx];
+    x.b0 = bias ? bias[r0] : 0.f;
+    x.b1 = bias ? bias[r1] : 0.f;
     return x;
   };
-  auto epi = [&](int p, float s0, float s1, const Aux& x) {
+  auto epi = [&](int p, float s0, float s1, const Aux& x) __attribute__((always_inline)) {
     if (lane != 0) return;
     int which, r0, r1, cidx;
     decode(p, which, r0, r1, cidx);
     // matmul.cpp:74-77: bias added after the matmul, before RoPE (x + 0.f is exact)
     s0 = s0 + x.b0;
     s1 = s1 + x.b1;
-    float* dst = which == 0 ? a.q_out
-                            : (which == 1 ? a.kcache_layer : a.vcache_layer) +
-                                  (size_t)pos * a.kv_dim;
+    float* dst = sel3(which, q_out, kc + (size_t)pos * kv_dim, vc + (size_t)pos * kv_dim);
     if (which < 2) {
       const float v0 = s0, v1 = s1;
       s0 = v0 * x.fcr - v1 * x.fci;
       s1 = v0 * x.fci + v1 * x.fcr;
     }
-    dst[r0] = s0;
-    dst[r1] = s1;
+    if (MERGED) {
+      st_sc1(dst + r0, s0);
+      st_sc1(dst + r1, s1);
+    } else {
+      dst[r0] = s0;
+      dst[r1] = s1;
+    }
   };
-  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + 4, pair, pre, [&] { st.issue(); },
-                              [&] { st.finish(xs, a.eps, red); }, epi);
+  // MERGED: an aligned block of 4 pairs never straddles a (projection, KV group) boundary: per
+  // group there are kv_mul*hs/2 q pairs and hs/2 k (v) pairs, all multiples of 4 (checked at
+  // model build), so one arrival per workgroup-iteration on the group's counter
+  auto after = [&](int pf) __attribute__((always_inline)) {
+    if (!MERGED) return;
+    int* cnt = nullptr;
+    if (pf >= 0) {
+      int which, r0, r1, cidx;
+      decode(pf, which, r0, r1, cidx);
+      const int grp = which == 0 ? (r0 / hs) / kv_mul : r0 / hs;
+      cnt = cnt_qkv + grp * KH_SYNC_STRIDE;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores are out
+    __syncthreads();
+    if (cnt && threadIdx.x == 0)
+      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + 4, pair, pre, [&]() __attribute__((always_inline)) { st.issue(); },
+                              [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi, vb, vgrid, after);
+}
+template <bool QUANT, int U, int MAXV, int SPLIT>
+__global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  qkv_body<QUANT, U, MAXV, SPLIT, false>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x, KhSync{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -145,22 +212,47 @@ struct KhAttnArgs {
   int kv_heads, nsplit;    // grid = kv_heads * kv_mul * nsplit workgroups
   void* ws;                // attn_ws_bytes(heads, head_size, nsplit), tickets zeroed
 };
-template <int G>
-__global__ __launch_bounds__(KH_WG) void k_attn(const KhAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+template <int G, bool MERGED>
+__device__ __forceinline__ void attn_body(const KhAttnArgs& a, char* smem_raw, int b,
+                                          const KhSync& sync) {
   const int pos = *a.d_pos;
   // block -> (kv group g, head-in-group j, split s): blocks are placed on XCD b % 8, so with
   // g = b % kv_heads the kv_mul heads that share K/V rows share an XCD's L2 (kv_heads % 8 == 0)
-  const int b = blockIdx.x;
   const int g = b % a.kv_heads;
   const int j = (b / a.kv_heads) % a.kv_mul;
   const int s = b / (a.kv_heads * a.kv_mul);
   const int h = g * a.kv_mul + j;
   const size_t head_off = (size_t)g * a.head_size;
-  attn_head_decode_fast<G>(a.q + (size_t)h * a.head_size, a.kcache_layer + head_off,
-                           a.vcache_layer + head_off, a.kv_dim, a.head_size, pos,
-                           a.out + (size_t)h * a.head_size, (float*)smem_raw, h, s, a.nsplit,
-                           attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.nsplit));
+  if (MERGED) {
+    // splits that have nothing to do at this position leave before touching any counter
+    if (s >= attn_active_splits(pos, a.nsplit)) return;
+  }
+  // MERGED: q and cache row `pos` of this KV group are being produced by the qkv stage of the
+  // same launch.  The core first puts the OLDER K/V rows of its first batch in flight (they do
+  // not depend on this launch), then calls this (bounded) wait, then reads q and row `pos` with
+  // sc1 loads.
+  const int* const cq = sync.cnt_qkv + g * KH_SYNC_STRIDE;
+  const int eq = sync.expect_qkv;
+  int* const err = sync.err;
+  auto wait = [&]() __attribute__((always_inline)) {
+    if (MERGED) wait_counter<8>(cq, eq, err);
+  };
+  const bool wrote = attn_head_decode_fast<G, MERGED>(
+      a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
+      a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, (float*)smem_raw, h, s,
+      a.nsplit, attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.nsplit), wait);
+  if (MERGED && wrote) {  // uniform per workgroup: one arrival on every replica
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < KH_SYNC_REPL)
+      __hip_atomic_fetch_add(sync.cnt_attn + threadIdx.x * KH_SYNC_STRIDE, 1, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <int G>
+__global__ __launch_bounds__(KH_WG) void k_attn(const KhAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  attn_body<G, false>(a, smem_raw, (int)blockIdx.x, KhSync{});
 }
 
 // head_size <= 32 (tiny test models): the generic LDS-score core of the op-level kernel
@@ -182,29 +274,54 @@ struct KhGemvResArgs {
   float* x;          // [K] residual stream, updated in place
   int M, K, gshift;
 };
-template <bool QUANT, int U, int MAXV, int SPLIT>
-__global__ __launch_bounds__(KH_WG) void k_gemv_res(const KhGemvResArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// MERGED: the input vector is produced earlier in the same launch (attention output): the first
+// weight chunk and the residual are fetched FIRST, then the workgroup waits (bounded) for the
+// producers' counter and stages the vector with sc1 loads.
+template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED>
+__device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem_raw, int vb,
+                                              int vgrid, const KhSync& sync) {
+  // scalar locals for everything the lambdas touch (see qkv_body)
+  const void* const w = a.w.w;
+  const float* const scales = a.w.scales;
+  float* const x = a.x;
+  const int M = a.M;
+  const int* const cnt_attn = sync.cnt_attn;
+  int* const err = sync.err;
+  const int expect_attn = sync.expect_attn;
   f32x4* xs = (f32x4*)smem_raw;
-  float* red = lds_red_ptr<QUANT>(xs, a.M);
+  float* red = lds_red_ptr<QUANT>(xs, M);
   const int lane = threadIdx.x & 63;
-  const Gemv<QUANT, U> g(a.M, a.gshift);
-  Stager<false, QUANT, MAXV> st(a.vec, nullptr, a.M);
-  auto pair = [&](int p) {
-    return g.rows(a.w.w, 2 * p, a.w.w, 2 * p + 1, a.w.scales, a.w.scales, a.M);
-  };
+  const Gemv<QUANT, U> g(M, a.gshift);
+  Stager<false, QUANT, MAXV, MERGED> st(a.vec, nullptr, M);
+  auto pair = [&](int p) __attribute__((always_inline)) { return g.rows(w, 2 * p, w, 2 * p + 1, scales, scales, M); };
   struct Aux {
     float x0, x1;
   };
-  auto pre = [&](int p) { return Aux{a.x[2 * p], a.x[2 * p + 1]}; };  // residual, fetched early
-  auto epi = [&](int p, float s0, float s1, const Aux& r) {
+  auto pre = [&](int p) __attribute__((always_inline)) { return Aux{x[2 * p], x[2 * p + 1]}; };  // residual, fetched early
+  auto epi = [&](int p, float s0, float s1, const Aux& r) __attribute__((always_inline)) {
     if (lane != 0) return;
-    a.x[2 * p] = r.x0 + s0;
-    a.x[2 * p + 1] = r.x1 + s1;
+    x[2 * p] = r.x0 + s0;
+    x[2 * p + 1] = r.x1 + s1;
   };
-  gemv_pairs<QUANT, U, SPLIT>(g, xs, a.K >> 1 /* K even, checked at model build */, lane,
-                              red + 4, pair, pre, [&] { st.issue(); },
-                              [&] { st.finish(xs, 0.f, red); }, epi);
+  gemv_pairs<QUANT, U, SPLIT>(
+      g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + 4, pair, pre,
+      [&]() __attribute__((always_inline)) {
+        if (!MERGED) st.issue();
+      },
+      [&]() __attribute__((always_inline)) {
+        if (MERGED) {
+          wait_counter<32>(cnt_attn + (vb & (KH_SYNC_REPL - 1)) * KH_SYNC_STRIDE, expect_attn, err);
+          st.issue();
+        }
+        st.finish(xs, 0.f, red);
+      },
+      epi, vb, vgrid);
+}
+template <bool QUANT, int U, int MAXV, int SPLIT>
+__global__ __launch_bounds__(KH_WG) void k_gemv_res(const KhGemvResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  gemv_res_body<QUANT, U, MAXV, SPLIT, false>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x,
+                                              KhSync{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,13 +341,13 @@ __global__ __launch_bounds__(KH_WG) void k_ffn13(const KhFfn13Args a) {
   const int lane = threadIdx.x & 63;
   const Gemv<QUANT, U> g(a.dim, a.gshift);
   Stager<true, QUANT, MAXV> st(a.x, a.ffn_norm, a.dim);
-  auto pair = [&](int r) { return g.rows(a.w1.w, r, a.w3.w, r, a.w1.scales, a.w3.scales, a.dim); };
-  auto epi = [&](int r, float s0, float s1, const NoAux&) {
+  auto pair = [&](int r) __attribute__((always_inline)) { return g.rows(a.w1.w, r, a.w3.w, r, a.w1.scales, a.w3.scales, a.dim); };
+  auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane == 0) a.h[r] = swiglu1(s0, s1);
   };
-  gemv_pairs<QUANT, U, 1>(g, xs, a.hidden, lane, nullptr, pair, [](int) { return NoAux{}; },
-                       [&] { st.issue(); },
-                       [&] { st.finish(xs, a.eps, red); }, epi);
+  gemv_pairs<QUANT, U, 1>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+                       [&]() __attribute__((always_inline)) { st.issue(); },
+                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -254,11 +371,11 @@ __global__ __launch_bounds__(KH_WG) void k_cls(const KhClsArgs a) {
   Stager<true, QUANT, MAXV> st(a.x, a.final_norm, a.dim);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  auto r1_of = [&](int p) { return 2 * p + 1 < a.vocab ? 2 * p + 1 : 2 * p; };
-  auto pair = [&](int p) {
+  auto r1_of = [&](int p) __attribute__((always_inline)) { return 2 * p + 1 < a.vocab ? 2 * p + 1 : 2 * p; };
+  auto pair = [&](int p) __attribute__((always_inline)) {
     return g.rows(a.wcls.w, 2 * p, a.wcls.w, r1_of(p), a.wcls.scales, a.wcls.scales, a.dim);
   };
-  auto epi = [&](int p, float s0, float s1, const NoAux&) {
+  auto epi = [&](int p, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane != 0) return;
     const int r0 = 2 * p, r1 = r1_of(p);
     a.logits[r0] = s0;
@@ -269,9 +386,9 @@ __global__ __launch_bounds__(KH_WG) void k_cls(const KhClsArgs a) {
     }
   };
   gemv_pairs<QUANT, U, 1>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
-                          [](int) { return NoAux{}; },
-                       [&] { st.issue(); },
-                       [&] { st.finish(xs, a.eps, red); }, epi);
+                          [](int) __attribute__((always_inline)) { return NoAux{}; },
+                       [&]() __attribute__((always_inline)) { st.issue(); },
+                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
   // stage-1 argmax: one partial per workgroup (ties -> lowest index)
   int* redi = (int*)(red + KH_WAVES_PER_WG + 8);
   __syncthreads();
@@ -309,8 +426,11 @@ struct KhSampleArgs {
   float* x;               // residual stream: receives the next token's embedding row
   int dim, vocab;
   int advance;            // 1: generate loop (feed next token, ++pos); 0: predict() only
+  int* sync_words;        // hand-off counters of the merged launches: re-armed every step
+  int n_sync;
 };
 __global__ __launch_bounds__(KH_WG) void k_sample(const KhSampleArgs a) {
+  for (int i = threadIdx.x; i < a.n_sync; i += KH_WG) a.sync_words[i] = 0;
   __shared__ float sv[KH_WAVES_PER_WG];
   __shared__ int si[KH_WAVES_PER_WG];
   __shared__ int s_next;

@@ -232,17 +232,27 @@ struct Gemv<true, U> {
 // columns; partial sums are combined through LDS in fixed order (deterministic).  Used when a
 // matrix has too few rows to put >= ~4096 waves in flight (w2: 1024 pairs of 32 KiB rows), where
 // one wave per pair leaves 4 waves per CU and no load/compute overlap.  comb = LDS float[8].
+// vb / vgrid: the (virtual) workgroup index and count of this GEMV stage — blockIdx.x/gridDim.x
+// for a stand-alone kernel, a sub-range of the grid when several stages share one launch
+// (kh_merged.h).  AFTER(p_first): called by ALL threads once per iteration after the epilogues
+// (p_first = the iteration's first pair of this workgroup, -1 if the workgroup had none); the
+// merged launch uses it to publish "these rows are done" to the consumer stage.
+struct NoAfter {
+  __device__ __forceinline__ void operator()(int) const {}
+};
 template <bool QUANT, int U, int SPLIT, class PairFn, class PreFn, class IssueFn, class FinishFn,
-          class EpiFn>
+          class EpiFn, class AfterFn = NoAfter>
 __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4* xs, int total,
                                            int lane, float* comb, PairFn&& PAIR, PreFn&& PRE,
-                                           IssueFn&& ISSUE, FinishFn&& FINISH, EpiFn&& EPI) {
+                                           IssueFn&& ISSUE, FinishFn&& FINISH, EpiFn&& EPI,
+                                           int vb = (int)blockIdx.x, int vgrid = (int)gridDim.x,
+                                           AfterFn&& AFTER = AfterFn()) {
   static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
   constexpr int PPW = KH_WAVES_PER_WG / SPLIT;  // pairs per workgroup per iteration
   const int wave = threadIdx.x >> 6;
   const int part = wave & (SPLIT - 1);
-  const int gp = blockIdx.x * PPW + wave / SPLIT;
-  const int np = gridDim.x * PPW;
+  const int gp = vb * PPW + wave / SPLIT;
+  const int np = vgrid * PPW;
   const int step = KH_WAVE * U;
   // column quantum per part, multiple of 4 chunks so an int8 part starts on a group boundary
   const int Q = (((g.Mc + SPLIT - 1) / SPLIT) + 3) & ~3;
@@ -300,6 +310,10 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
       }
       __syncthreads();
     }
+    {
+      const int pf = vb * PPW + it * np;  // first pair of this workgroup in this iteration
+      AFTER(pf < total ? pf : -1);
+    }
     aux = aux_next;
   }
 }
@@ -350,7 +364,10 @@ __device__ __forceinline__ void stage_vec(const float* __restrict__ x,
 // waitcnt merge degrades to vmcnt(0) = "wait for the weights too"):
 //   MAXV = 4  vectors up to 4096 floats (dim of every BASELINE config)
 //   MAXV = 0  any length: single-phase stage_vec after the first weight loads were issued
-template <bool NORM, bool LAYOUT_Q8, int MAXV>
+// SC1: the vector was written earlier in the SAME launch by other workgroups with write-through
+// (sc1) stores; it is then read with agent-scope relaxed atomic loads (sc1: bypass the
+// non-coherent L1 / remote-L2 copies) instead of plain loads (kh_merged.h).
+template <bool NORM, bool LAYOUT_Q8, int MAXV, bool SC1 = false>
 struct Stager {
   f32x4 xv[MAXV > 0 ? MAXV : 1];
   f32x4 wv[(NORM && MAXV > 0) ? MAXV : 1];
@@ -368,7 +385,7 @@ struct Stager {
       for (int v = 0; v < MAXV; ++v) {
         const int i = threadIdx.x + v * KH_WG;
         const int ci = i < M4 ? i : 0;
-        xv[v] = x4[ci];
+        xv[v] = SC1 ? ld4_sc1(x4 + ci) : x4[ci];
         if (NORM) wv[v] = w4[ci];
       }
     }

@@ -20,7 +20,7 @@
 #include <thread>
 #include <vector>
 
-#include "kh_fused.h"
+#include "kh_merged.h"
 
 namespace {
 
@@ -53,6 +53,9 @@ struct kh_model {
   int32_t* part_idx = nullptr;
   int nparts = 0;
   float load_ms = 0.f;      // host image -> HBM upload time (kh_model_get_load_ms)
+  int* sync_words = nullptr;  // hand-off counters of the merged launches + 1 error word
+  int n_sync = 0;
+  int merge_combo = -1;       // kh_merged.h combination id, -1 = stand-alone kernels
   void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
   int attn_ns = 1;
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
@@ -190,7 +193,7 @@ int ilog2_exact(int v) {
 #define KH_DISPATCH4(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
   KH_SEL_U(KH_SEL_MV4, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
 
-void launch_qkv(kh_model* m, int l) {
+KhQkvArgs fill_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const LayerW& W = m->layers[l];
   KhQkvArgs a;
@@ -211,11 +214,16 @@ void launch_qkv(kh_model* m, int l) {
   a.rope_mode = c.rope_mode;
   a.gshift = m->gshift;
   a.eps = c.rms_eps;
+  return a;
+}
+void launch_qkv(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const KhQkvArgs a = fill_qkv(m, l);
   const bool qn = c.is_quant;
   KH_DISPATCH4(k_qkv, qn, m->sh_qkv.u, kh_stage_maxv(c.dim), m->sh_qkv.split, m->sh_qkv.grid,
                fused_lds_bytes(qn, c.dim), m->stream, a);
 }
-void launch_attn(kh_model* m, int l) {
+KhAttnArgs fill_attn(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   KhAttnArgs a;
   a.q = m->q;
@@ -229,6 +237,16 @@ void launch_attn(kh_model* m, int l) {
   a.kv_heads = c.kv_head_num;
   a.nsplit = m->attn_ns;
   a.ws = m->attn_ws;
+  return a;
+}
+int attn_group_lanes(const kh_config& c) {
+  int G = 1;
+  while (G < c.head_size / 4) G <<= 1;
+  return G < 16 ? 16 : G;
+}
+void launch_attn(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const KhAttnArgs a = fill_attn(m, l);
   int G = 1;
   while (G < c.head_size / 4) G <<= 1;
   const size_t lds = attn_fast_lds_bytes(c.head_size);
@@ -243,7 +261,7 @@ void launch_attn(kh_model* m, int l) {
     hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(KH_WG),
                        attn_lds_bytes(c.head_size), m->stream, a);
 }
-void launch_wo(kh_model* m, int l) {
+KhGemvResArgs fill_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   KhGemvResArgs a;
   a.vec = m->att;
@@ -252,6 +270,11 @@ void launch_wo(kh_model* m, int l) {
   a.M = c.dim;
   a.K = c.dim;
   a.gshift = m->gshift;
+  return a;
+}
+void launch_wo(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const KhGemvResArgs a = fill_wo(m, l);
   const bool qn = c.is_quant;
   KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim), m->sh_wo.split, m->sh_wo.grid,
                fused_lds_bytes(qn, c.dim), m->stream, a);
@@ -322,23 +345,53 @@ void launch_sample(kh_model* m, int advance, int n_forced) {
   a.dim = c.dim;
   a.vocab = c.vocab_size;
   a.advance = advance;
+  a.sync_words = m->sync_words;
+  a.n_sync = m->n_sync;  // re-arms every hand-off counter (not the error word)
   hipLaunchKernelGGL(k_sample, dim3(1), dim3(KH_WG), 0, m->stream, a);
 }
 
-// one fused decode step = 5L + 2 launches.  ev (optional) receives an event after each launch.
+// [qkv | attention | wo] of layer l as ONE launch with in-launch hand-offs (kh_merged.h)
+void launch_layer_a_merged(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  KhLayerAArgs a;
+  a.qkv = fill_qkv(m, l);
+  a.attn = fill_attn(m, l);
+  a.wo = fill_wo(m, l);
+  int* base = m->sync_words + (size_t)l * (c.kv_head_num + KH_SYNC_REPL) * KH_SYNC_STRIDE;
+  a.sync.cnt_qkv = base;
+  a.sync.cnt_attn = base + (size_t)c.kv_head_num * KH_SYNC_STRIDE;
+  a.sync.err = m->sync_words + m->n_sync;
+  const int ppw = KH_WAVES_PER_WG / m->sh_qkv.split;
+  a.sync.expect_qkv = (c.kv_mul * c.head_size / 2 + c.head_size) / ppw;
+  a.sync.expect_attn = c.head_num;
+  a.n_qkv = m->sh_qkv.grid;
+  a.n_attn = c.head_num * m->attn_ns;
+  a.n_wo = m->sh_wo.grid;
+  size_t lds = fused_lds_bytes(c.is_quant, c.dim);
+  if (attn_fast_lds_bytes(c.head_size) > lds) lds = attn_fast_lds_bytes(c.head_size);
+  launch_layer_a(m->merge_combo, a.n_qkv + a.n_attn + a.n_wo, lds, m->stream, a);
+}
+
+// one fused decode step = 5L + 2 launches (3L + 2 with the merged [qkv|attn|wo] launch).
+// ev (optional) receives an event after each launch; event timing always uses the 5-kernel form.
 void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev) {
   int e = 0;
   auto mark = [&]() {
     if (ev) (void)hipEventRecord(ev[e++], m->stream);
   };
   mark();
+  const bool merged = m->merge_combo >= 0 && !ev;
   for (int l = 0; l < m->cfg.layer_num; ++l) {
-    launch_qkv(m, l);
-    mark();
-    launch_attn(m, l);
-    mark();
-    launch_wo(m, l);
-    mark();
+    if (merged) {
+      launch_layer_a_merged(m, l);
+    } else {
+      launch_qkv(m, l);
+      mark();
+      launch_attn(m, l);
+      mark();
+      launch_wo(m, l);
+      mark();
+    }
     launch_ffn13(m, l);
     mark();
     launch_w2(m, l);
@@ -448,6 +501,18 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
   if (ms_out)
     *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return e;
+}
+
+// after a synchronised run: did any bounded in-launch wait time out?  (re-arms the word)
+int check_sync_err(kh_model* m) {
+  if (m->merge_combo < 0) return KH_OK;
+  int h = 0;
+  KH_CHECK_HIP(hipMemcpyAsync(&h, m->sync_words + m->n_sync, sizeof(int), hipMemcpyDeviceToHost,
+                              m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  if (h == 0) return KH_OK;
+  KH_CHECK_HIP(hipMemsetAsync(m->sync_words + m->n_sync, 0, sizeof(int), m->stream));
+  return KH_ERR_SYNC;
 }
 
 template <typename T>
@@ -657,6 +722,22 @@ int finish_create(kh_model* m) {
   m->sh_w2 = pick_shape(c.is_quant, c.dim / 2, c.hidden_dim, 4, "KH_SHAPE_W2");
   m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS");
   m->nparts = m->sh_cls.grid;
+  m->n_sync = c.layer_num * (c.kv_head_num + KH_SYNC_REPL) * KH_SYNC_STRIDE;
+  KH_CHECK_HIP(hipMalloc((void**)&m->sync_words, sizeof(int) * (size_t)(m->n_sync + 1)));
+  KH_CHECK_HIP(hipMemsetAsync(m->sync_words, 0, sizeof(int) * (size_t)(m->n_sync + 1), m->stream));
+  m->merge_combo = -1;
+  {
+    // merged [qkv|attn|wo] launch: only for instantiated shapes, dim within the in-register
+    // staging depth, pair blocks that do not straddle KV groups; opt-in (KH_FLAG_MERGE / KH_MERGE=1)
+    const char* env = getenv("KH_MERGE");
+    const bool off = !((m->opts.flags & KH_FLAG_MERGE) || (env && env[0] == '1'));
+    const int ppw = KH_WAVES_PER_WG / m->sh_qkv.split;
+    const bool aligned = ((c.kv_mul * c.head_size / 2) % 4 == 0) && ((c.head_size / 2) % 4 == 0) &&
+                         ((c.kv_mul * c.head_size / 2 + c.head_size) % ppw == 0);
+    if (!off && c.head_size > 32 && kh_stage_maxv(c.dim) == 4 && aligned)
+      m->merge_combo = merged_combo_id(c.is_quant, m->sh_qkv.u, m->sh_qkv.split,
+                                       attn_group_lanes(c), m->sh_wo.u, m->sh_wo.split);
+  }
   m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
   if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ns)) {
     KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
@@ -750,7 +831,7 @@ extern "C" void kh_model_destroy(kh_model* m) {
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
                   m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
                   m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
-                  m->d_forced, m->d_words, m->attn_ws};
+                  m->d_forced, m->d_words, m->attn_ws, m->sync_words};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (m->owns_arena && m->arena) (void)hipFree(m->arena);
@@ -851,6 +932,8 @@ extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* 
 extern "C" int kh_model_get_config(const kh_model* m, kh_config* out) {
   if (!m || !out) return KH_ERR_INVALID_ARG;
   *out = m->cfg;
+  out->merged_launch = m->merge_combo >= 0;
+  out->launches_per_token = (m->merge_combo >= 0 ? 3 : 5) * m->cfg.layer_num + 2;
   return KH_OK;
 }
 extern "C" float kh_model_get_load_ms(const kh_model* m) { return m ? m->load_ms : -1.f; }
@@ -904,7 +987,7 @@ extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t
   KH_CHECK_HIP(hipMemcpyAsync(&next, m->d_next, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   *h_next = is_prompt ? -1 : next;  // post_processing (llama3.cpp:733-745)
-  return KH_OK;
+  return check_sync_err(m);
 }
 
 extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
@@ -974,7 +1057,7 @@ extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
   *n_words = total_steps;
-  return KH_OK;
+  return check_sync_err(m);
 }
 
 static const char* const kKClassNames[KH_NUM_KCLASS] = {"qkv", "attn", "wo", "ffn13", "w2", "cls",

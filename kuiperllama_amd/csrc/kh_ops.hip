@@ -96,16 +96,16 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_f32(const float* __restrict__ 
   const int lane = threadIdx.x & 63;
   const Gemv<false, U> g(M, 0);
   Stager<false, false, MAXV> st(x, nullptr, M);
-  auto r1_of = [&](int p) { return 2 * p + 1 < K ? 2 * p + 1 : 2 * p; };
-  auto pair = [&](int p) { return g.rows(w, 2 * p, w, r1_of(p), nullptr, nullptr, M); };
-  auto epi = [&](int p, float s0, float s1, const NoAux&) {
+  auto r1_of = [&](int p) __attribute__((always_inline)) { return 2 * p + 1 < K ? 2 * p + 1 : 2 * p; };
+  auto pair = [&](int p) __attribute__((always_inline)) { return g.rows(w, 2 * p, w, r1_of(p), nullptr, nullptr, M); };
+  auto epi = [&](int p, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane != 0) return;
     const int r0 = 2 * p, r1 = r1_of(p);
     y[r0] = s0 * scale;
     if (r1 != r0) y[r1] = s1 * scale;
   };
-  gemv_pairs<false, U, 1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) { return NoAux{}; },
-                       [&] { st.issue(); }, [&] { st.finish(xs, 0.f, red); }, epi);
+  gemv_pairs<false, U, 1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+                       [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
 }
 
 // any M / any alignment (also M too large for LDS): wave per row, scalar lane-strided loads
@@ -176,16 +176,16 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_q8(const float* __restrict__ x
   const int lane = threadIdx.x & 63;
   const Gemv<true, U> g(M, gshift);
   Stager<false, true, MAXV> st(x, nullptr, M);
-  auto r1_of = [&](int p) { return 2 * p + 1 < K ? 2 * p + 1 : 2 * p; };
-  auto pair = [&](int p) { return g.rows(w, 2 * p, w, r1_of(p), scales, scales, M); };
-  auto epi = [&](int p, float s0, float s1, const NoAux&) {
+  auto r1_of = [&](int p) __attribute__((always_inline)) { return 2 * p + 1 < K ? 2 * p + 1 : 2 * p; };
+  auto pair = [&](int p) __attribute__((always_inline)) { return g.rows(w, 2 * p, w, r1_of(p), scales, scales, M); };
+  auto epi = [&](int p, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane != 0) return;
     const int r0 = 2 * p, r1 = r1_of(p);
     y[r0] = s0;
     if (r1 != r0) y[r1] = s1;
   };
-  gemv_pairs<true, U, 1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) { return NoAux{}; },
-                      [&] { st.issue(); }, [&] { st.finish(xs, 0.f, red); }, epi);
+  gemv_pairs<true, U, 1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+                      [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
 }
 
 // literal restatement of the reference formula for any M/group/alignment
@@ -632,6 +632,7 @@ extern "C" const char* kh_error_string(int code) {
     case KH_ERR_FORMAT: return "malformed model image";
     case KH_ERR_NO_DEVICE: return "no HIP device";
     case KH_ERR_RANGE: return "token or position out of range";
+    case KH_ERR_SYNC: return "in-launch hand-off timed out";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -16,9 +16,12 @@ from ._ffi import KH_EXEC_FUSED, KH_EXEC_GRAPH, KH_EXEC_UNFUSED  # noqa: F401
 EXEC = {"graph": KH_EXEC_GRAPH, "fused": KH_EXEC_FUSED, "unfused": KH_EXEC_UNFUSED}
 
 
-def _opts(spec: binfmt.ModelSpec, max_seq_len: int, device: int) -> _ffi.ModelOpts:
+KH_FLAG_MERGE = 2  # experimental merged [qkv|attention|wo] launch (off by default)
+
+
+def _opts(spec: binfmt.ModelSpec, max_seq_len: int, device: int, flags: int = 0) -> _ffi.ModelOpts:
     return _ffi.ModelOpts(spec.family, int(spec.quant), spec.rope_mode, spec.rope_theta,
-                          spec.rms_eps, max_seq_len, device, 0)
+                          spec.rms_eps, max_seq_len, device, flags)
 
 
 class KuiperModel:
@@ -35,19 +38,19 @@ class KuiperModel:
     # ---- construction ------------------------------------------------------------------
     @classmethod
     def from_file(cls, path: str, spec: binfmt.ModelSpec, max_seq_len: int = 0,
-                  device: int = 0) -> "KuiperModel":
+                  device: int = 0, flags: int = 0) -> "KuiperModel":
         h = C.c_void_p()
-        o = _opts(spec, max_seq_len, device)
+        o = _opts(spec, max_seq_len, device, flags)
         _ffi.check(_ffi.lib().kh_model_create_from_file(path.encode(), C.byref(o), C.byref(h)),
                    "kh_model_create_from_file")
         return cls(h.value, spec)
 
     @classmethod
     def from_host_image(cls, image: np.ndarray, spec: binfmt.ModelSpec, max_seq_len: int = 0,
-                        device: int = 0) -> "KuiperModel":
+                        device: int = 0, flags: int = 0) -> "KuiperModel":
         assert image.dtype == np.uint8 and image.flags["C_CONTIGUOUS"]
         h = C.c_void_p()
-        o = _opts(spec, max_seq_len, device)
+        o = _opts(spec, max_seq_len, device, flags)
         _ffi.check(_ffi.lib().kh_model_create_from_host_image(image.ctypes.data, image.size,
                                                               C.byref(o), C.byref(h)),
                    "kh_model_create_from_host_image")
@@ -55,7 +58,7 @@ class KuiperModel:
 
     @classmethod
     def from_device_image(cls, image: torch.Tensor, spec: binfmt.ModelSpec, max_seq_len: int = 0,
-                          device: int = 0) -> "KuiperModel":
+                          device: int = 0, flags: int = 0) -> "KuiperModel":
         """image: uint8 GPU tensor with the .bin bytes (header included).  The weights are
         re-based once so that the data after the header is 256-byte aligned, then used in
         place (not copied again, not owned by the library)."""
@@ -71,7 +74,7 @@ class KuiperModel:
             keep = weights
         torch.cuda.synchronize()
         h = C.c_void_p()
-        o = _opts(spec, max_seq_len, device)
+        o = _opts(spec, max_seq_len, device, flags)
         hdr = (C.c_int32 * 8)(*header.tolist()[:8])
         _ffi.check(_ffi.lib().kh_model_create_from_device_weights(hdr, weights.data_ptr(),
                                                                   weights.numel(), C.byref(o),
