@@ -200,11 +200,36 @@ int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows, fl
 
 /* demo/main.cpp:5-47 generate(): prompt fed one token per step without sampling, then
  * greedy decode, `total_steps` forward passes in total; h_words receives the reference's
- * `words` vector.  No stop-token check (tokeniser is out of scope).  *h_elapsed_ms = wall
+ * `words` vector.  No stop-token check (see kh_model_generate_until).  *h_elapsed_ms = wall
  * time of the step loop measured with HIP events on the model stream. */
 int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
                       int32_t total_steps, int32_t exec, int32_t* h_words, int32_t* n_words,
                       float* h_elapsed_ms);
+/* The same loop with the reference's stop check (demo/main.cpp:30-32, Model::is_sentence_ending
+ * model.cpp:211-214): generation ends at the first SAMPLED token that is in h_stop[0..n_stop)
+ * (SentencePiece: eos_id, encode.cpp:48-51; BPE: two stop tokens, encode.cpp:133-139); that token
+ * is not appended to `words`, *n_words = the reference's return value min(pos, total_steps).
+ * Graph mode checks chunk k's words from pinned memory while chunk k+1 is already queued, so
+ * there is no per-token host round trip; at most 2*8 steps run past the stop and are discarded. */
+int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
+                            int32_t total_steps, int32_t exec, const int32_t* h_stop,
+                            int32_t n_stop, int32_t* h_words, int32_t* n_words,
+                            float* h_elapsed_ms);
+
+/* Average duration of ONE kernel class launched back to back (no event between launches, so
+ * no event overhead in the figure): the kernel is enqueued for layers 0..L-1 `reps` times
+ * between two HIP events on the model stream (cls / sample: `reps` launches); consecutive
+ * launches read different layers' weights, so nothing is served from cache.  This is the
+ * number bench.py's roofline uses and the one rocprofv3's per-kernel average must agree with.
+ * Destroys the activation state and KV row `pos` (a later generate/predict resets both). */
+int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos, int32_t reps,
+                            float* h_avg_us);
+
+/* Latency of ONE decode step at position `pos` (per-token latency at pos 0/64/127):
+ * the 1-step hipGraph replayed `reps` times with the device state reset to `pos` before each,
+ * HIP events around each replay; h_us[reps] in microseconds.  KV rows below pos must exist and
+ * a graph-mode generate of more than `pos` steps must have run on this model. */
+int kh_model_time_step(kh_model* m, int32_t pos, int32_t reps, float* h_us);
 
 /* Per-kernel-class timing of the fused step with HIP events (eager launches, one event
  * between every kernel).  n_steps decode steps starting at position start_pos (KV rows

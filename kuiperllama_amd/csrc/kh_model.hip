@@ -61,6 +61,9 @@ struct kh_model {
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
+  int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check)
+  int pin_cap = 0;
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   // launch geometry
   struct Shape {
     int u = 2, split = 1, grid = 1;
@@ -521,6 +524,20 @@ int dalloc(T** p, size_t n) {
   return e == hipSuccess ? KH_OK : (int)e;
 }
 
+int ensure_pinned_words(kh_model* m, int n) {
+  for (auto& e : m->ev_chunk)
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipErrorUnknown;
+  if (n <= m->pin_cap) return KH_OK;
+  if (m->h_words_pin) (void)hipHostFree(m->h_words_pin);
+  m->h_words_pin = nullptr;
+  m->pin_cap = 0;
+  if (hipHostMalloc((void**)&m->h_words_pin, sizeof(int32_t) * (size_t)n, hipHostMallocDefault) !=
+      hipSuccess)
+    return (int)hipErrorUnknown;
+  m->pin_cap = n;
+  return KH_OK;
+}
+
 int ensure_seq_cap(kh_model* m, int n) {
   if (n <= m->seq_cap) return KH_OK;
   if (m->d_forced) (void)hipFree(m->d_forced);
@@ -828,6 +845,9 @@ extern "C" void kh_model_destroy(kh_model* m) {
   if (m->graphN) (void)hipGraphDestroy(m->graphN);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
+  for (auto e : m->ev_chunk)
+    if (e) (void)hipEventDestroy(e);
+  if (m->h_words_pin) (void)hipHostFree(m->h_words_pin);
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
                   m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
                   m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
@@ -993,7 +1013,24 @@ extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t
 extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
                                  int32_t total_steps, int32_t exec, int32_t* h_words,
                                  int32_t* n_words, float* h_elapsed_ms) {
-  if (!m || !h_prompt || n_prompt <= 0 || total_steps <= 0 || !h_words || !n_words)
+  return kh_model_generate_until(m, h_prompt, n_prompt, total_steps, exec, nullptr, 0, h_words,
+                                 n_words, h_elapsed_ms);
+}
+
+namespace {
+inline bool is_stop(int32_t t, const int32_t* stop, int n_stop) {
+  for (int i = 0; i < n_stop; ++i)
+    if (stop[i] == t) return true;
+  return false;
+}
+}  // namespace
+
+extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
+                                       int32_t total_steps, int32_t exec, const int32_t* h_stop,
+                                       int32_t n_stop, int32_t* h_words, int32_t* n_words,
+                                       float* h_elapsed_ms) {
+  if (!m || !h_prompt || n_prompt <= 0 || total_steps <= 0 || !h_words || !n_words ||
+      n_stop < 0 || (n_stop > 0 && !h_stop))
     return KH_ERR_INVALID_ARG;
   const kh_config& c = m->cfg;
   if (total_steps > c.cache_len) return KH_ERR_RANGE;
@@ -1012,6 +1049,8 @@ extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n
       const int tok = pos <= n_prompt - 1 ? h_prompt[pos] : next;
       int got = -1;
       if ((rc = kh_model_predict(m, tok, pos, is_prompt, KH_EXEC_UNFUSED, &got)) != KH_OK) return rc;
+      // demo/main.cpp:30-32: only a sampled token can end the sentence (next == -1 in the prompt)
+      if (!is_prompt && is_stop(got, h_stop, n_stop)) break;
       next = is_prompt ? h_prompt[pos + 1] : got;
       h_words[nw++] = next;
       pos += 1;
@@ -1036,27 +1075,125 @@ extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n
 
   set_state(m, h_prompt[0], 0);
   KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
-  for (int s = 0; s < total_steps;) {
+  auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps
     if (exec == KH_EXEC_GRAPH) {
       if (total_steps - s >= KH_GRAPH_STEPS) {
-        KH_CHECK_HIP(hipGraphLaunch(m->gexecN, m->stream));
-        s += KH_GRAPH_STEPS;
-      } else {
-        KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
-        s += 1;
+        if (hipGraphLaunch(m->gexecN, m->stream) != hipSuccess) return -1;
+        return KH_GRAPH_STEPS;
       }
-    } else {
-      launch_step_fused(m, 1, n_forced, nullptr);
-      s += 1;
+      if (hipGraphLaunch(m->gexec, m->stream) != hipSuccess) return -1;
+      return 1;
     }
+    launch_step_fused(m, 1, n_forced, nullptr);
+    return 1;
+  };
+  int n_out = total_steps;
+  if (n_stop == 0) {
+    for (int s = 0; s < total_steps;) {
+      const int n = launch_chunk(s);
+      if (n < 0) return (int)hipErrorUnknown;
+      s += n;
+    }
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+    if ((rc = kh_launch_status()) != KH_OK) return rc;
+    KH_CHECK_HIP(hipMemcpyAsync(h_words, m->d_words, sizeof(int32_t) * total_steps,
+                                hipMemcpyDeviceToHost, m->stream));
+    KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  } else {
+    // Stop-token check without a per-step host round trip: the words of every
+    // chunk of steps are mirrored into pinned memory behind the chunk, and the host inspects
+    // chunk k while chunk k+1 is already queued, so the GPU never waits for the check.  At
+    // most two chunks of steps run past the stop token; their words are discarded.
+    if ((rc = ensure_pinned_words(m, total_steps)) != KH_OK) return rc;
+    struct Chunk { int s0, n; };
+    Chunk infl[2];
+    int n_infl = 0, head = 0, launched = 0, stop_at = -1;
+    while (stop_at < 0 && (launched < total_steps || n_infl > 0)) {
+      while (launched < total_steps && n_infl < 2) {
+        const int n = launch_chunk(launched);
+        if (n < 0) return (int)hipErrorUnknown;
+        const int slot = (head + n_infl) & 1;
+        KH_CHECK_HIP(hipMemcpyAsync(m->h_words_pin + launched, m->d_words + launched,
+                                    sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+        KH_CHECK_HIP(hipEventRecord(m->ev_chunk[slot], m->stream));
+        infl[slot] = {launched, n};
+        launched += n;
+        ++n_infl;
+      }
+      KH_CHECK_HIP(hipEventSynchronize(m->ev_chunk[head]));
+      const Chunk c0 = infl[head];
+      for (int s = c0.s0; s < c0.s0 + c0.n; ++s)
+        if (s >= n_prompt - 1 && is_stop(m->h_words_pin[s], h_stop, n_stop)) {
+          stop_at = s;
+          break;
+        }
+      if (stop_at >= 0) {
+        // the loop time the reference would report ends with the step that produced the stop
+        KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));  // (after the queued overshoot)
+      }
+      head ^= 1;
+      --n_infl;
+    }
+    if (stop_at < 0) KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+    if ((rc = kh_launch_status()) != KH_OK) return rc;
+    KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    n_out = stop_at >= 0 ? stop_at : total_steps;
+    memcpy(h_words, m->h_words_pin, sizeof(int32_t) * (size_t)n_out);
   }
-  KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
-  if ((rc = kh_launch_status()) != KH_OK) return rc;
-  KH_CHECK_HIP(hipMemcpyAsync(h_words, m->d_words, sizeof(int32_t) * total_steps,
-                              hipMemcpyDeviceToHost, m->stream));
-  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
-  *n_words = total_steps;
+  *n_words = n_out;
+  return check_sync_err(m);
+}
+
+extern "C" int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos, int32_t reps,
+                                       float* h_avg_us) {
+  if (!m || !h_avg_us || reps <= 0 || kclass < 0 || kclass >= KH_NUM_KCLASS)
+    return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if (pos < 0 || pos >= c.cache_len) return KH_ERR_RANGE;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  set_state(m, 1 % c.vocab_size, pos);
+  const bool per_layer = kclass < KH_K_CLS;
+  const int n_inner = per_layer ? c.layer_num : 1;
+  auto sweep = [&]() {
+    for (int l = 0; l < n_inner; ++l) switch (kclass) {
+        case KH_K_QKV: launch_qkv(m, l); break;
+        case KH_K_ATTN: launch_attn(m, l); break;
+        case KH_K_WO: launch_wo(m, l); break;
+        case KH_K_FFN13: launch_ffn13(m, l); break;
+        case KH_K_W2: launch_w2(m, l); break;
+        case KH_K_CLS: launch_cls(m); break;
+        default: launch_sample(m, /*advance=*/0, /*n_forced=*/0); break;
+      }
+  };
+  sweep();  // untimed: first-touch effects
+  KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+  for (int r = 0; r < reps; ++r) sweep();
+  KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+  KH_CHECK_HIP(hipEventSynchronize(m->ev1));
+  int rc = kh_launch_status();
+  if (rc != KH_OK) return rc;
+  float ms = 0.f;
+  KH_CHECK_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+  *h_avg_us = ms * 1e3f / (float)(reps * n_inner);
+  return check_sync_err(m);
+}
+
+extern "C" int kh_model_time_step(kh_model* m, int32_t pos, int32_t reps, float* h_us) {
+  if (!m || !h_us || reps <= 0) return KH_ERR_INVALID_ARG;
+  if (pos < 0 || pos >= m->cfg.cache_len || pos >= m->seq_cap) return KH_ERR_RANGE;
+  if (!m->gexec) return KH_ERR_INVALID_ARG;  // a graph-mode generate must have run
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  for (int r = 0; r < reps; ++r) {
+    set_state(m, 1 % m->cfg.vocab_size, pos);
+    KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+    KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+    KH_CHECK_HIP(hipEventSynchronize(m->ev1));
+    float ms = 0.f;
+    KH_CHECK_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+    h_us[r] = ms * 1e3f;
+  }
   return check_sync_err(m);
 }
 

@@ -119,17 +119,39 @@ class KuiperModel:
         return k, v
 
     # ---- demo/main.cpp generate() ---------------------------------------------------------
-    def generate(self, prompt: Sequence[int], total_steps: int, exec: str = "graph"
-                 ) -> Tuple[List[int], float]:
-        """Returns (words, elapsed_ms of the step loop measured with HIP events)."""
+    def generate(self, prompt: Sequence[int], total_steps: int, exec: str = "graph",
+                 stop: Optional[Sequence[int]] = None) -> Tuple[List[int], float]:
+        """Returns (words, elapsed_ms of the step loop measured with HIP events).  `stop` = the
+        reference's sentence-ending token ids (demo/main.cpp:30-32); the stop token itself is not
+        part of `words`."""
         pr = (C.c_int32 * len(prompt))(*[int(t) for t in prompt])
+        st = list(stop or [])
+        sp = (C.c_int32 * max(len(st), 1))(*[int(t) for t in st])
         words = (C.c_int32 * total_steps)()
         n = C.c_int32(0)
         ms = C.c_float(0.0)
-        _ffi.check(_ffi.lib().kh_model_generate(self._h, pr, len(prompt), total_steps, EXEC[exec],
-                                                words, C.byref(n), C.byref(ms)),
-                   "kh_model_generate")
+        _ffi.check(_ffi.lib().kh_model_generate_until(self._h, pr, len(prompt), total_steps,
+                                                      EXEC[exec], sp, len(st), words,
+                                                      C.byref(n), C.byref(ms)),
+                   "kh_model_generate_until")
         return list(words[: n.value]), float(ms.value)
+
+    def time_step(self, pos: int, reps: int = 9) -> List[float]:
+        """Microseconds of one graph-replayed decode step at `pos`, `reps` samples."""
+        us = (C.c_float * reps)()
+        _ffi.check(_ffi.lib().kh_model_time_step(self._h, pos, reps, us), "kh_model_time_step")
+        return [float(v) for v in us]
+
+    def profile_kernels(self, pos: int, reps: int = 8):
+        """Back-to-back average launch duration (us) of every kernel class at position `pos`
+        (kh_model_profile_kernel); clobbers activations and KV row `pos`."""
+        out = {}
+        for i in range(_ffi.KH_NUM_KCLASS):
+            us = C.c_float(0.0)
+            _ffi.check(_ffi.lib().kh_model_profile_kernel(self._h, i, pos, reps, C.byref(us)),
+                       "kh_model_profile_kernel")
+            out[_ffi.lib().kh_kclass_name(i).decode()] = float(us.value)
+        return out
 
     def profile_step(self, start_pos: int, n_steps: int):
         """Per-kernel-class average launch duration (us) of the fused step, HIP events."""

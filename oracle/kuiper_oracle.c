@@ -82,8 +82,22 @@ static float arma_accumulate(const float* x, int n) {
 /* ---- cpu/matmul_kernel.cpp:5-41 ---------------------------------------------------
  * weight is [K rows, M cols] row-major (wei_dim0=K, wei_dim1=M); arma views it as M x K
  * column-major, so output[p] = sum_i input[i]*weight[p*M+i]; then "* scale" (line 40). */
+/* Timing-only variant (bench.py cpu_baseline): the reference's CPU matmul is
+ * Armadillo -> BLAS sgemv (cpu/matmul_kernel.cpp:37-40), so a caller may plug in a
+ * cblas_sgemv-compatible ILP64 entry point (numpy's bundled OpenBLAS).  Never set by tests:
+ * BLAS summation order is not the pinned one. */
+typedef void (*ko_sgemv_fn)(int order, int trans, int64_t m, int64_t n, float alpha,
+                            const float* a, int64_t lda, const float* x, int64_t incx, float beta,
+                            float* y, int64_t incy);
+static ko_sgemv_fn g_sgemv = NULL;
+void ko_set_sgemv(void* fn) { g_sgemv = (ko_sgemv_fn)fn; }
+
 void ko_matmul_f32(const float* x, const float* w, float* y, int M, int K, float scale,
                    int acc) {
+  if (g_sgemv && acc == KO_ACC_F32) {
+    g_sgemv(101 /*RowMajor*/, 111 /*NoTrans*/, K, M, scale, w, M, x, 1, 0.f, y, 1);
+    return;
+  }
 #pragma omp parallel for schedule(static) if (K >= 64)
   for (int p = 0; p < K; ++p) {
     const float* row = w + (size_t)p * (size_t)M;
@@ -570,20 +584,31 @@ int ko_model_forward(ko_model* m, int32_t token, int32_t pos, int acc) {
 /* demo/main.cpp:5-47 */
 int ko_model_generate(ko_model* m, const int32_t* prompt, int n_prompt, int total_steps,
                       int32_t* out_words, int acc) {
+  return ko_model_generate_until(m, prompt, n_prompt, total_steps, NULL, 0, out_words, acc);
+}
+
+int ko_model_generate_until(ko_model* m, const int32_t* prompt, int n_prompt, int total_steps,
+                            const int32_t* stop, int n_stop, int32_t* out_words, int acc) {
   if (n_prompt <= 0) return -1;
   int pos = 0, nw = 0;
   int32_t next = -1;
   while (pos < total_steps) {
-    if (pos < n_prompt - 1) {
+    const int is_prompt = pos < n_prompt - 1;
+    if (is_prompt) {
       if (ko_model_forward(m, prompt[pos], pos, acc)) return -1;
-      next = prompt[pos + 1]; /* is_prompt: sampling skipped, next forced (:36-38) */
     } else {
       /* at pos == n_prompt-1 the reference's `next` holds tokens[pos] (set by the previous
        * prompt iteration, or by main_qwen.cpp:12 for a 1-token prompt) */
       const int32_t tok = (pos == n_prompt - 1) ? prompt[n_prompt - 1] : next;
       if (ko_model_forward(m, tok, pos, acc)) return -1;
       next = (int32_t)ko_argmax_f32(m->logits, (size_t)m->c.vocab_size);
+      /* demo/main.cpp:30-32 is_sentence_ending(next): in the prompt phase post_processing
+       * returned -1 (llama3.cpp:736-737), so only a sampled token can end the loop */
+      int hit = 0;
+      for (int i = 0; i < n_stop; ++i) hit |= (stop[i] == next);
+      if (hit) break;
     }
+    if (is_prompt) next = prompt[pos + 1]; /* sampling skipped, next forced (:33-35) */
     out_words[nw++] = next;
     pos += 1;
   }

@@ -33,6 +33,8 @@ enum { KO_ACC_F32 = 0, KO_ACC_F64 = 1 };
 enum { KO_FAMILY_LLAMA = 0, KO_FAMILY_QWEN2 = 1 };
 
 /* ---------------- op level (one per reference CPU kernel) ---------------- */
+/* timing only: route fp32 matmuls through a cblas_sgemv (ILP64) entry point; NULL = off */
+void ko_set_sgemv(void* cblas_sgemv64_fn);
 void ko_set_threads(int n);
 int ko_get_threads(void);
 
@@ -107,6 +109,9 @@ float* ko_model_vcache(ko_model* m);
  * *returned list*; the forward sequence is identical. */
 int ko_model_generate(ko_model* m, const int32_t* prompt, int n_prompt, int total_steps,
                       int32_t* out_words, int acc);
+/* the same loop with the stop check of demo/main.cpp:30-32 (the stop token is not appended) */
+int ko_model_generate_until(ko_model* m, const int32_t* prompt, int n_prompt, int total_steps,
+                            const int32_t* stop, int n_stop, int32_t* out_words, int acc);
 
 #ifdef __cplusplus
 }

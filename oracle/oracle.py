@@ -112,6 +112,9 @@ def lib() -> C.CDLL:
         L.ko_model_vcache.restype = _fp
         L.ko_model_generate.argtypes = [C.c_void_p, _i32p, C.c_int, C.c_int, _i32p, C.c_int]
         L.ko_model_generate.restype = C.c_int
+        L.ko_model_generate_until.argtypes = [C.c_void_p, _i32p, C.c_int, C.c_int, _i32p, C.c_int,
+                                              _i32p, C.c_int]
+        L.ko_model_generate_until.restype = C.c_int
         _lib = L
     return _lib
 
@@ -123,6 +126,37 @@ def _f(a: np.ndarray):
 
 def f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+_blas = None
+
+
+def use_openblas(threads: int) -> bool:
+    """Timing only (bench.py): route the oracle's fp32 matmuls through the OpenBLAS that ships
+    inside numpy (ILP64 `scipy_cblas_sgemv64_`), mirroring the reference CPU backend's
+    Armadillo -> BLAS sgemv (cpu/matmul_kernel.cpp:37-40).  threads <= 0 switches it off.
+    Returns False when no such library is present."""
+    global _blas
+    L = lib()
+    L.ko_set_sgemv.argtypes = [C.c_void_p]
+    if threads <= 0:
+        L.ko_set_sgemv(None)
+        return True
+    if _blas is None:
+        import glob
+        cands = glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs",
+                                       "libscipy_openblas64_*.so"))
+        if not cands:
+            return False
+        _blas = C.CDLL(cands[0])
+    try:
+        fn = C.cast(_blas.scipy_cblas_sgemv64_, C.c_void_p)
+        _blas.scipy_openblas_set_num_threads64_.argtypes = [C.c_int]
+        _blas.scipy_openblas_set_num_threads64_(int(threads))
+    except AttributeError:
+        return False
+    L.ko_set_sgemv(fn)
+    return True
 
 
 def set_threads(n: int) -> None:
@@ -272,11 +306,14 @@ class OracleModel:
         v = np.ctypeslib.as_array(lib().ko_model_vcache(self._h), shape=shp)
         return k, v
 
-    def generate(self, prompt: Sequence[int], total_steps: int, acc: int = ACC_F32):
+    def generate(self, prompt: Sequence[int], total_steps: int, acc: int = ACC_F32,
+                 stop: Sequence[int] = ()):
         pr = np.ascontiguousarray(prompt, dtype=np.int32)
+        st = np.ascontiguousarray(list(stop) or [0], dtype=np.int32)
         out = np.empty(total_steps, np.int32)
-        n = lib().ko_model_generate(self._h, pr.ctypes.data_as(_i32p), pr.size, total_steps,
-                                    out.ctypes.data_as(_i32p), acc)
+        n = lib().ko_model_generate_until(self._h, pr.ctypes.data_as(_i32p), pr.size, total_steps,
+                                          st.ctypes.data_as(_i32p), len(list(stop)),
+                                          out.ctypes.data_as(_i32p), acc)
         if n < 0:
             raise ValueError("oracle generate failed")
         return out[:n].tolist()

@@ -63,6 +63,35 @@ def test_generate_modes_agree_with_oracle(gpu, oracle, name):
     m.close()
 
 
+@pytest.mark.parametrize("name", ["ref_llama_gqa_tied", "hf_qwen2_half"])
+def test_generate_stop_tokens(gpu, oracle, name):
+    """demo/main.cpp:30-32: the loop ends at the first SAMPLED stop token, which is not appended;
+    a stop id inside the prompt does not end it (post_processing returns -1 there)."""
+    from kuiperllama_amd.model import KuiperModel
+    spec, img, toks, _ = load_golden(name)
+    steps = spec.seq_len
+    prompt = [int(t) for t in toks[:3]]
+    om = oracle.OracleModel.from_spec(img, spec)
+    full = om.generate(prompt, steps)
+    m = KuiperModel.from_host_image(img, spec)
+    # stop tokens taken from the free-running sequence at several depths (inside the first graph
+    # chunk, at a chunk edge, deep), plus one that never occurs and one that is a prompt token
+    sampled = full[len(prompt) - 1:]
+    cases = [[sampled[0]], [sampled[7]], [sampled[8]], [sampled[min(29, len(sampled) - 1)], -5],
+             [spec.vocab_size + 7], [prompt[1]]]
+    for stop in cases:
+        want = om.generate(prompt, steps, stop=stop)
+        first = next((i for i in range(len(prompt) - 1, steps) if full[i] in stop), steps)
+        assert want == full[:first]
+        for mode in ("graph", "fused", "unfused"):
+            got, ms = m.generate(prompt, steps, exec=mode, stop=stop)
+            assert got == want, (name, stop, mode, len(got), len(want))
+    # the model is reusable after an early stop
+    again, _ = m.generate(prompt, steps)
+    assert again == full
+    m.close()
+
+
 def test_kv_cache_matches_oracle(gpu, oracle):
     from kuiperllama_amd.model import KuiperModel
     spec, img, toks, _ = load_golden("hf_llama_half")

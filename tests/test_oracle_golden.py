@@ -138,3 +138,17 @@ def test_generate_loop_semantics(oracle):
         if pos + 1 >= len(seq):
             seq.append(int(np.argmax(lg)))
     assert seq[1:11] == words
+
+
+def test_oracle_generate_stop_semantics(oracle):
+    """demo/main.cpp:30-32: break on a sampled stop token before it is appended."""
+    spec, img, toks, _ = load_golden("ref_llama_gqa_tied")
+    om = oracle.OracleModel.from_spec(img, spec)
+    prompt = [int(t) for t in toks[:3]]
+    full = om.generate(prompt, 24)
+    assert full[:2] == prompt[1:]
+    k = 9
+    got = om.generate(prompt, 24, stop=[full[k]])
+    first = next(i for i in range(2, 24) if full[i] == full[k])
+    assert got == full[:first]
+    assert om.generate(prompt, 24, stop=[prompt[1]])[:2] == prompt[1:]  # prompt ids never stop it

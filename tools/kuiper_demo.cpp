@@ -4,7 +4,7 @@
 // scope, so the prompt is given as token ids and ids are printed.
 //
 //   kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]
-//               [--theta 10000] [--eps 1e-5] [--steps 128] [--prompt 1,263]
+//               [--theta 10000] [--eps 1e-5] [--steps 128] [--prompt 1,263] [--stop 2]
 //               [--exec graph|fused|unfused] [--max-seq-len N] [--device 0]
 //
 // Prints the generated ids and "steps/s" like demo/main.cpp:70-72.
@@ -20,7 +20,7 @@
 static void usage() {
   std::fprintf(stderr,
                "usage: kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]\n"
-               "       [--theta F] [--eps F] [--steps N] [--prompt id,id,...] [--exec graph|fused|unfused]\n"
+               "       [--theta F] [--eps F] [--steps N] [--prompt id,id,...] [--stop id,id] [--exec graph|fused|unfused]\n"
                "       [--max-seq-len N] [--device D]\n");
 }
 
@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
   const char* path = argv[1];
   kh_model_opts o{KH_FAMILY_LLAMA, 0, KH_ROPE_INTERLEAVED, 10000.f, 1e-5f, 0, 0, 0};
   int steps = 128, exec = KH_EXEC_GRAPH;
+  std::vector<int32_t> stop;  // is_sentence_ending ids (main.cpp:30): eos / <|eot_id|> / ...
   std::vector<int32_t> prompt{1, 263};  // BOS + "a": the reference demo's prompt (main.cpp:64)
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
@@ -53,14 +54,15 @@ int main(int argc, char** argv) {
     else if (a == "--exec") {
       std::string e = next();
       exec = e == "unfused" ? KH_EXEC_UNFUSED : (e == "fused" ? KH_EXEC_FUSED : KH_EXEC_GRAPH);
-    } else if (a == "--prompt") {
-      prompt.clear();
+    } else if (a == "--prompt" || a == "--stop") {
+      std::vector<int32_t>& dst = a == "--prompt" ? prompt : stop;
+      dst.clear();
       std::string s = next();
       size_t p = 0;
       while (p < s.size()) {
         size_t q = s.find(',', p);
         if (q == std::string::npos) q = s.size();
-        prompt.push_back(std::atoi(s.substr(p, q - p).c_str()));
+        dst.push_back(std::atoi(s.substr(p, q - p).c_str()));
         p = q + 1;
       }
     } else {
@@ -86,7 +88,8 @@ int main(int argc, char** argv) {
   float gpu_ms = 0.f;
   std::printf("Generating...\n");
   const auto t0 = std::chrono::steady_clock::now();  // timer excludes init (main.cpp:66)
-  rc = kh_model_generate(m, prompt.data(), (int32_t)prompt.size(), steps, exec, words.data(), &n, &gpu_ms);
+  rc = kh_model_generate_until(m, prompt.data(), (int32_t)prompt.size(), steps, exec, stop.data(),
+                               (int32_t)stop.size(), words.data(), &n, &gpu_ms);
   const auto t1 = std::chrono::steady_clock::now();
   if (rc != KH_OK) {
     std::fprintf(stderr, "generate failed: %d (%s)\n", rc, kh_error_string(rc));
