@@ -18,8 +18,8 @@
 
 #define KH_ATTN_TC 2048  // timesteps per LDS score chunk (8 KiB)
 
-static inline size_t attn_lds_bytes(int head_size) {
-  return (size_t)(KH_ATTN_TC + 8 + KH_WAVES_PER_WG * head_size) * sizeof(float);
+static inline size_t attn_lds_bytes(int head_size, int wg = KH_WG) {
+  return (size_t)(KH_ATTN_TC + 8 + (wg / KH_WAVE) * head_size) * sizeof(float);
 }
 
 // q_h: [hs] ; k_base/v_base: cache + layer offset + head column offset ; kv_stride = kv_dim.
@@ -37,7 +37,7 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
   const int hs4 = hs >> 2;
   int G = 1;
   while (G < hs4) G <<= 1;             // lanes per timestep (<= 64 since hs <= 256)
-  const int TPI = KH_WG / G;           // timesteps per workgroup iteration
+  const int TPI = kh_wg() / G;         // timesteps per workgroup iteration
   const int tg = tid / G, dl = tid - tg * G;
   const bool active = dl < hs4;
   const int stride4 = kv_stride >> 2;
@@ -78,11 +78,11 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
     __syncthreads();
     // ---- running softmax statistics --------------------------------------------------------
     float mx = -INFINITY;
-    for (int t = tid; t < tc; t += KH_WG) mx = fmaxf(mx, sc[t]);
+    for (int t = tid; t < tc; t += kh_wg()) mx = fmaxf(mx, sc[t]);
     mx = block_max(mx, red);
     const float m_new = fmaxf(m_run, mx);
     float s = 0.f;
-    for (int t = tid; t < tc; t += KH_WG) {
+    for (int t = tid; t < tc; t += kh_wg()) {
       const float e = expf(sc[t] - m_new);
       sc[t] = e;
       s += e;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
     m_run = m_new;
     if (single) {
       // one chunk: normalise BEFORE the weighted sum like cpu/softmax_kernel.cpp:13-14
-      for (int t = tid; t < tc; t += KH_WG) sc[t] = sc[t] / s;
+      for (int t = tid; t < tc; t += kh_wg()) sc[t] = sc[t] / s;
       __syncthreads();
     }
     // ---- o += sum_t p[t] * V[t] --------------------------------------------------------------
@@ -133,13 +133,13 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
     float r = 0.f;
     // when G == 256/TPI... every wave holds a partial for every d (TPI >= 4 <=> G <= 64)
 #pragma unroll
-    for (int w = 0; w < KH_WAVES_PER_WG; ++w) r += opart[w * hs + tid];
+    for (int w = 0, nw = kh_nwaves(); w < nw; ++w) r += opart[w * hs + tid];
     out_h[tid] = single ? r : r / l_run;
   }
   if (score_out) {
     // probabilities as the reference leaves them in the score tensor
     const float inv_l = l_run;
-    for (int t = tid; t < nT; t += KH_WG) score_out[t] = expf(score_out[t] - m_run) / inv_l;
+    for (int t = tid; t < nT; t += kh_wg()) score_out[t] = expf(score_out[t] - m_run) / inv_l;
   }
 }
 
@@ -166,8 +166,8 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 #define KH_ATTN_UB 4
 #define KH_ATTN_MIN_TS 256  // timesteps per split before a second split is opened
 #define KH_ATTN_MAX_NS 16
-static inline size_t attn_fast_lds_bytes(int head_size) {
-  return (size_t)(8 + 8 + KH_WAVES_PER_WG * head_size) * sizeof(float);
+static inline size_t attn_fast_lds_bytes(int head_size, int wg = KH_WG) {
+  return (size_t)(8 + 8 + (wg / KH_WAVE) * head_size) * sizeof(float);
 }
 // splits per head carried by the grid for a cache of `cache_len` rows
 static inline int attn_num_splits(int cache_len) {
@@ -224,7 +224,7 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
                                                    float* smem, float& r_out, float& L_out,
                                                    WaitFn&& WAIT) {
   static_assert(G == 16 || G == 32 || G == 64, "G must be 16, 32 or 64");
-  constexpr int TPI = KH_WG / G;
+  const int TPI = kh_wg() / G;
   float* red = smem;          // [8]
   float* lpart = smem + 8;    // [8]
   float* opart = smem + 16;   // [4][hs]
@@ -301,8 +301,7 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   __syncthreads();
   float r = 0.f, L = 0.f;
   if (tid < hs) {
-#pragma unroll
-    for (int w = 0; w < KH_WAVES_PER_WG; ++w) {
+    for (int w = 0, nw = kh_nwaves(); w < nw; ++w) {
       r += opart[w * hs + tid];
       L += lpart[w];
     }

@@ -7,8 +7,15 @@
 #include "../../include/kuiper_hip.h"
 
 #define KH_WAVE 64
+#ifndef KH_WG
 #define KH_WG 256
+#endif
 #define KH_WAVES_PER_WG (KH_WG / KH_WAVE)
+// The fused decode kernels read their workgroup size from blockDim.x (256 or 512 threads, chosen
+// per launch: a wider workgroup halves the per-launch re-staging of a long input vector, see
+// pick_shape); KH_WG is the default and the size every op-level kernel uses.
+#define KH_WG_MAX 512
+#define KH_WAVES_MAX (KH_WG_MAX / KH_WAVE)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -178,7 +185,10 @@ __device__ __forceinline__ float across_groups_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
-// Sum over a 256-thread workgroup; every thread gets the result. red = LDS float[4+].
+__device__ __forceinline__ int kh_wg() { return (int)blockDim.x; }
+__device__ __forceinline__ int kh_nwaves() { return (int)(blockDim.x >> 6); }
+
+// Sum over the workgroup; every thread gets the result. red = LDS float[KH_WAVES_MAX+].
 // Two barriers so `red` can be reused immediately afterwards.
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
@@ -186,8 +196,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   if (lane == 0) red[wave] = v;
   __syncthreads();
   float r = 0.f;
-#pragma unroll
-  for (int w = 0; w < KH_WAVES_PER_WG; ++w) r += red[w];
+  for (int w = 0, n = kh_nwaves(); w < n; ++w) r += red[w];
   __syncthreads();
   return r;
 }
@@ -197,8 +206,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   if (lane == 0) red[wave] = v;
   __syncthreads();
   float r = red[0];
-#pragma unroll
-  for (int w = 1; w < KH_WAVES_PER_WG; ++w) r = fmaxf(r, red[w]);
+  for (int w = 1, n = kh_nwaves(); w < n; ++w) r = fmaxf(r, red[w]);
   __syncthreads();
   return r;
 }

@@ -33,9 +33,9 @@ template <bool QUANT>
 __device__ __forceinline__ float* lds_red_ptr(f32x4* xs, int M) {
   return (float*)(xs + (QUANT ? 4 * ((M >> 4) + 1) : (M >> 2)));
 }
-// xs | red[4] | comb[8] (split-row partial sums)
+// xs | red[KH_WAVES_MAX] | comb[2*KH_WAVES_MAX] (split-row partial sums)
 static inline size_t fused_lds_bytes(bool quant, int M) {
-  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 16 + 32;
+  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 3 * KH_WAVES_MAX * sizeof(float);
 }
 
 // Three-way select on VALUES.  Written as `w == 0 ? a : ...` directly on named variables, the
@@ -192,11 +192,11 @@ __device__ __forceinline__ void qkv_body(const KhQkvArgs& a, char* smem_raw, int
     if (cnt && threadIdx.x == 0)
       __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + 4, pair, pre, [&]() __attribute__((always_inline)) { st.issue(); },
+  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre, [&]() __attribute__((always_inline)) { st.issue(); },
                               [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi, vb, vgrid, after);
 }
 template <bool QUANT, int U, int MAXV, int SPLIT>
-__global__ __launch_bounds__(KH_WG) void k_qkv(const KhQkvArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   qkv_body<QUANT, U, MAXV, SPLIT, false>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x, KhSync{});
 }
@@ -250,13 +250,13 @@ __device__ __forceinline__ void attn_body(const KhAttnArgs& a, char* smem_raw, i
   }
 }
 template <int G>
-__global__ __launch_bounds__(KH_WG) void k_attn(const KhAttnArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX) void k_attn(const KhAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   attn_body<G, false>(a, smem_raw, (int)blockIdx.x, KhSync{});
 }
 
 // head_size <= 32 (tiny test models): the generic LDS-score core of the op-level kernel
-__global__ __launch_bounds__(KH_WG) void k_attn_generic(const KhAttnArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX) void k_attn_generic(const KhAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int pos = *a.d_pos;
   const int h = blockIdx.x;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem
     x[2 * p + 1] = r.x1 + s1;
   };
   gemv_pairs<QUANT, U, SPLIT>(
-      g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + 4, pair, pre,
+      g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) {
         if (!MERGED) st.issue();
       },
@@ -318,7 +318,7 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem
       epi, vb, vgrid);
 }
 template <bool QUANT, int U, int MAXV, int SPLIT>
-__global__ __launch_bounds__(KH_WG) void k_gemv_res(const KhGemvResArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   gemv_res_body<QUANT, U, MAXV, SPLIT, false>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x,
                                               KhSync{});
@@ -334,7 +334,7 @@ struct KhFfn13Args {
   float eps;
 };
 template <bool QUANT, int U, int MAXV>
-__global__ __launch_bounds__(KH_WG) void k_ffn13(const KhFfn13Args a) {
+__global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
@@ -362,7 +362,7 @@ struct KhClsArgs {
   float eps;
 };
 template <bool QUANT, int U, int MAXV>
-__global__ __launch_bounds__(KH_WG) void k_cls(const KhClsArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(KH_WG) void k_cls(const KhClsArgs a) {
                        [&]() __attribute__((always_inline)) { st.issue(); },
                        [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
   // stage-1 argmax: one partial per workgroup (ties -> lowest index)
-  int* redi = (int*)(red + KH_WAVES_PER_WG + 8);
+  int* redi = (int*)(red + 3 * KH_WAVES_MAX);
   __syncthreads();
   if (lane == 0) {
     red[wave] = bv;
@@ -400,14 +400,13 @@ __global__ __launch_bounds__(KH_WG) void k_cls(const KhClsArgs a) {
   if (threadIdx.x == 0) {
     float v = red[0];
     int i = redi[0];
-#pragma unroll
-    for (int w = 1; w < KH_WAVES_PER_WG; ++w) amax_merge(v, i, red[w], redi[w]);
+    for (int w = 1, nw = kh_nwaves(); w < nw; ++w) amax_merge(v, i, red[w], redi[w]);
     a.part_val[blockIdx.x] = v;
     a.part_idx[blockIdx.x] = i;
   }
 }
 static inline size_t cls_lds_bytes(bool quant, int M) {
-  return fused_lds_bytes(quant, M) + 2 * KH_WAVES_PER_WG * sizeof(float);
+  return fused_lds_bytes(quant, M) + KH_WAVES_MAX * sizeof(int);
 }
 
 // ---------------------------------------------------------------------------------------------

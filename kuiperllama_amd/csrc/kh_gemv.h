@@ -248,7 +248,7 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
                                            int vb = (int)blockIdx.x, int vgrid = (int)gridDim.x,
                                            AfterFn&& AFTER = AfterFn()) {
   static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
-  constexpr int PPW = KH_WAVES_PER_WG / SPLIT;  // pairs per workgroup per iteration
+  const int PPW = kh_nwaves() / SPLIT;  // pairs per workgroup per iteration
   const int wave = threadIdx.x >> 6;
   const int part = wave & (SPLIT - 1);
   const int gp = vb * PPW + wave / SPLIT;
@@ -334,7 +334,7 @@ __device__ __forceinline__ void stage_vec(const float* __restrict__ x,
   float rs = 1.f;
   if (NORM) {
     float ss = 0.f;
-    for (int i = threadIdx.x; i < M4; i += KH_WG) {
+    for (int i = threadIdx.x; i < M4; i += kh_wg()) {
       const f32x4 v = x4[i];
       ss = fma4(v, v, ss);
     }
@@ -344,7 +344,7 @@ __device__ __forceinline__ void stage_vec(const float* __restrict__ x,
   }
   const f32x4* w4 = (const f32x4*)wnorm;
   const int M16 = M >> 4;
-  for (int i = threadIdx.x; i < M4; i += KH_WG) {
+  for (int i = threadIdx.x; i < M4; i += kh_wg()) {
     f32x4 v = x4[i];
     if (NORM) {
       const f32x4 w = w4[i];
@@ -383,7 +383,7 @@ struct Stager {
       const f32x4* w4 = (const f32x4*)wnorm;
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
-        const int i = threadIdx.x + v * KH_WG;
+        const int i = threadIdx.x + v * kh_wg();
         const int ci = i < M4 ? i : 0;
         xv[v] = SC1 ? ld4_sc1(x4 + ci) : x4[ci];
         if (NORM) wv[v] = w4[ci];
@@ -401,14 +401,14 @@ struct Stager {
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
           const float t = fma4(xv[v], xv[v], 0.f);
-          ss += (threadIdx.x + v * KH_WG < M4) ? t : 0.f;
+          ss += (threadIdx.x + v * kh_wg() < M4) ? t : 0.f;
         }
         ss = block_sum(ss, red);
         rs = 1.0f / sqrtf(ss / (float)M + eps);
       }
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
-        const int i = threadIdx.x + v * KH_WG;
+        const int i = threadIdx.x + v * kh_wg();
         if (i < M4) {
           f32x4 t = xv[v];
           if (NORM) {
@@ -424,4 +424,4 @@ struct Stager {
     }
   }
 };
-static inline int kh_stage_maxv(int M) { return M <= 4 * 4 * KH_WG ? 4 : 0; }
+static inline int kh_stage_maxv(int M, int wg = KH_WG) { return M <= 4 * 4 * wg ? 4 : 0; }

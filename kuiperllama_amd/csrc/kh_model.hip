@@ -58,6 +58,7 @@ struct kh_model {
   int merge_combo = -1;       // kh_merged.h combination id, -1 = stand-alone kernels
   void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
   int attn_ns = 1;
+  int attn_wg = KH_WG;
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
@@ -66,7 +67,7 @@ struct kh_model {
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   // launch geometry
   struct Shape {
-    int u = 2, split = 1, grid = 1;
+    int u = 2, split = 1, grid = 1, wg = KH_WG;
   };
   Shape sh_qkv, sh_wo, sh_ffn, sh_w2, sh_cls;
   // graph
@@ -85,17 +86,21 @@ namespace {
 //         would still stream >= 8 KiB (fp32) / 4 KiB (int8);
 //  u    : 16-byte loads per row per lane in flight (covers the wave's column range when it can);
 //  grid : workgroups, <= 1024 (4 per CU), chosen so every wave gets the same number of items.
-kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const char* env) {
+kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const char* env,
+                           int wg = KH_WG, int wg_max = KH_WG, bool many_waves = false) {
   kh_model::Shape sh;
-  // tuning hook (tools/sweep_shapes.py): KH_SHAPE_<K>="split,u,grid" overrides the heuristic
+  sh.wg = wg;
+  // tuning hook (tools/sweep_shapes.py): KH_SHAPE_<K>="split,u,grid[,wg]" overrides the heuristic
   if (const char* ov = env ? getenv(env) : nullptr) {
-    int sp = 0, u = 0, g = 0;
-    if (sscanf(ov, "%d,%d,%d", &sp, &u, &g) == 3 && (sp == 1 || sp == 2 || sp == 4) &&
-        sp <= max_split && (u == 2 || u == 4 || u == 8) && !(quant && u == 8) && g >= 1 &&
-        g <= 4096) {
+    int sp = 0, u = 0, g = 0, w = wg;
+    const int nf = sscanf(ov, "%d,%d,%d,%d", &sp, &u, &g, &w);
+    if (nf >= 3 && (sp == 1 || sp == 2 || sp == 4) && sp <= max_split &&
+        (u == 2 || u == 4 || u == 8) && !(quant && u == 8) && g >= 1 && g <= 4096 &&
+        (w == 256 || (w == 512 && wg_max >= 512))) {
       sh.split = sp;
       sh.u = u;
       sh.grid = g;
+      sh.wg = w;
       return sh;
     }
   }
@@ -112,27 +117,40 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
     sh.u = per_lane >= 3 ? 4 : 2;
   else
     sh.u = per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
-  const int ppw = KH_WAVES_PER_WG / sh.split;  // pairs per workgroup per iteration
+  const int ppw = (wg / KH_WAVE) / sh.split;  // pairs per workgroup per iteration
   const int need = (pairs + ppw - 1) / ppw;
   // every workgroup re-stages the M-float input vector from L2: keep that below ~75 % of the
   // weight bytes (matters for w2, whose input is the hidden-sized vector; sweep in
   // profiles/r1_shape_sweep.md), and never more than 4 workgroups per CU
   long cap = (long)(0.75 * (double)pairs * (double)pair_bytes / ((double)M * 4.0));
-  if (cap > 1024) cap = 1024;
-  if (cap < 256) cap = 256;
+  const long cap_hi = 1024L * KH_WG / wg, cap_lo = 256L * KH_WG / wg;  // 4 .. 1 x 256 threads / CU
+  if (cap > cap_hi) cap = cap_hi;
+  if (cap < cap_lo) cap = cap_lo;
   if (need <= cap) {
     sh.grid = need;
   } else {
-    long best_waste = -1;
-    for (long g = cap; g >= cap / 2; --g) {
-      const long iters = (need + g - 1) / g;
-      const long waste = iters * g - need;
-      if (best_waste < 0 || waste < best_waste) {
-        best_waste = waste;
+    // several iterations per workgroup: keep the grid a whole number of workgroups per CU (256
+    // CUs; 384- or 688-wide grids measured 5-10 % slower than their balanced neighbours) and
+    // minimise the per-CU critical path (g/256)*ceil(need/g).  Ties: the many-row matrices
+    // (qkv, ffn13, cls) prefer 8 resident waves per CU, then 12, 16 -- fewer, longer-lived
+    // workgroups re-stage x less often; the few-long-row matrices (wo, w2: one or two chunks
+    // per wave) prefer 16 -- everything is in flight at once (profiles/r1_shape_sweep.md).
+    const int wpw = wg / KH_WAVE;           // waves per workgroup
+    // resident waves per CU, in order of preference
+    const int pref_lo[4] = {8, 12, 16, 4}, pref_hi[4] = {16, 12, 8, 4};
+    long best_cost = -1;
+    for (int wv : (many_waves ? pref_hi : pref_lo)) {
+      if (wv == 4 && best_cost >= 0) break;  // 4 waves per CU only when nothing else fits
+      if (wv % wpw) continue;
+      const long g = 256L * (wv / wpw);
+      if (g > cap) continue;
+      const long cost = g * ((need + g - 1) / g);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
         sh.grid = (int)g;
       }
-      if (waste == 0) break;
     }
+    if (best_cost < 0) sh.grid = (int)cap;
   }
   return sh;
 }
@@ -147,10 +165,11 @@ int ilog2_exact(int v) {
 // ---- fused launches -------------------------------------------------------------------------
 // Template dispatch.  U: 16-byte loads per row in flight per lane; MV: in-register staging depth
 // (kh_stage_maxv of the input length); SP: waves sharing one row pair.
+// The workgroup size comes from a variable `kh_launch_wg` in scope at the dispatch site.
 #define KH_L3(KERNEL, Q, UU, MV, GRID, LDS, STREAM, ARGS) \
-  hipLaunchKernelGGL((KERNEL<Q, UU, MV>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS)
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
 #define KH_L4(KERNEL, Q, UU, MV, SP, GRID, LDS, STREAM, ARGS) \
-  hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP>), dim3(GRID), dim3(KH_WG), LDS, STREAM, ARGS)
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
 #define KH_SEL_MV3(KERNEL, Q, UU, MV, ...)                  \
   do {                                                      \
     if ((MV) == 4)                                          \
@@ -223,7 +242,8 @@ void launch_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const KhQkvArgs a = fill_qkv(m, l);
   const bool qn = c.is_quant;
-  KH_DISPATCH4(k_qkv, qn, m->sh_qkv.u, kh_stage_maxv(c.dim), m->sh_qkv.split, m->sh_qkv.grid,
+  const int kh_launch_wg = m->sh_qkv.wg;
+  KH_DISPATCH4(k_qkv, qn, m->sh_qkv.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_qkv.split, m->sh_qkv.grid,
                fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 KhAttnArgs fill_attn(kh_model* m, int l) {
@@ -252,17 +272,18 @@ void launch_attn(kh_model* m, int l) {
   const KhAttnArgs a = fill_attn(m, l);
   int G = 1;
   while (G < c.head_size / 4) G <<= 1;
-  const size_t lds = attn_fast_lds_bytes(c.head_size);
+  const int wg = m->attn_wg;
+  const size_t lds = attn_fast_lds_bytes(c.head_size, wg);
   const dim3 grid(c.head_num * m->attn_ns);
   if (G <= 16 && c.head_size > 32)
-    hipLaunchKernelGGL(k_attn<16>, grid, dim3(KH_WG), lds, m->stream, a);
+    hipLaunchKernelGGL(k_attn<16>, grid, dim3(wg), lds, m->stream, a);
   else if (G == 32)
-    hipLaunchKernelGGL(k_attn<32>, grid, dim3(KH_WG), lds, m->stream, a);
+    hipLaunchKernelGGL(k_attn<32>, grid, dim3(wg), lds, m->stream, a);
   else if (G == 64)
-    hipLaunchKernelGGL(k_attn<64>, grid, dim3(KH_WG), lds, m->stream, a);
+    hipLaunchKernelGGL(k_attn<64>, grid, dim3(wg), lds, m->stream, a);
   else  // head_size <= 32: generic LDS-score kernel (tiny test models)
-    hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(KH_WG),
-                       attn_lds_bytes(c.head_size), m->stream, a);
+    hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(wg),
+                       attn_lds_bytes(c.head_size, wg), m->stream, a);
 }
 KhGemvResArgs fill_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -279,7 +300,8 @@ void launch_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const KhGemvResArgs a = fill_wo(m, l);
   const bool qn = c.is_quant;
-  KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim), m->sh_wo.split, m->sh_wo.grid,
+  const int kh_launch_wg = m->sh_wo.wg;
+  KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_wo.split, m->sh_wo.grid,
                fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 void launch_ffn13(kh_model* m, int l) {
@@ -296,7 +318,8 @@ void launch_ffn13(kh_model* m, int l) {
   a.gshift = m->gshift;
   a.eps = c.rms_eps;
   const bool qn = c.is_quant;
-  KH_DISPATCH3(k_ffn13, qn, m->sh_ffn.u, kh_stage_maxv(c.dim), m->sh_ffn.grid,
+  const int kh_launch_wg = m->sh_ffn.wg;
+  KH_DISPATCH3(k_ffn13, qn, m->sh_ffn.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_ffn.grid,
                fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 void launch_w2(kh_model* m, int l) {
@@ -309,7 +332,8 @@ void launch_w2(kh_model* m, int l) {
   a.K = c.dim;
   a.gshift = m->gshift;
   const bool qn = c.is_quant;
-  KH_DISPATCH4(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim), m->sh_w2.split, m->sh_w2.grid,
+  const int kh_launch_wg = m->sh_w2.wg;
+  KH_DISPATCH4(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split, m->sh_w2.grid,
                fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
 }
 void launch_cls(kh_model* m) {
@@ -327,7 +351,8 @@ void launch_cls(kh_model* m) {
   a.eps = c.rms_eps;
   // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
   const bool qn = c.is_quant;
-  KH_DISPATCH3(k_cls, qn, m->sh_cls.u, kh_stage_maxv(c.dim), m->sh_cls.grid, cls_lds_bytes(qn, c.dim),
+  const int kh_launch_wg = m->sh_cls.wg;
+  KH_DISPATCH3(k_cls, qn, m->sh_cls.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_cls.grid, cls_lds_bytes(qn, c.dim),
                m->stream, a);
 }
 void launch_sample(kh_model* m, int advance, int n_forced) {
@@ -733,11 +758,16 @@ int finish_create(kh_model* m) {
   KH_ALLOC(m->d_token, 1);
   KH_ALLOC(m->d_next, 1);
   // launch geometry
-  m->sh_qkv = pick_shape(c.is_quant, (c.dim + 2 * c.kv_dim) / 2, c.dim, 2, "KH_SHAPE_QKV");
-  m->sh_wo = pick_shape(c.is_quant, c.dim / 2, c.dim, 4, "KH_SHAPE_WO");
-  m->sh_ffn = pick_shape(c.is_quant, c.hidden_dim, c.dim, 1, "KH_SHAPE_FFN");
-  m->sh_w2 = pick_shape(c.is_quant, c.dim / 2, c.hidden_dim, 4, "KH_SHAPE_W2");
-  m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS");
+  m->sh_qkv = pick_shape(c.is_quant, (c.dim + 2 * c.kv_dim) / 2, c.dim, 2, "KH_SHAPE_QKV", KH_WG,
+                         KH_WG_MAX);
+  m->sh_wo = pick_shape(c.is_quant, c.dim / 2, c.dim, 4, "KH_SHAPE_WO", KH_WG, KH_WG_MAX, true);
+  m->sh_ffn = pick_shape(c.is_quant, c.hidden_dim, c.dim, 1, "KH_SHAPE_FFN", KH_WG, KH_WG_MAX);
+  // w2 re-stages the hidden-sized input in every workgroup: 512-thread workgroups halve that
+  // L2 -> LDS traffic for the same number of waves (measured 14.1 -> 11.8 us on Llama-3.2-1B)
+  m->sh_w2 = pick_shape(c.is_quant, c.dim / 2, c.hidden_dim, 4, "KH_SHAPE_W2", KH_WG_MAX, KH_WG_MAX,
+                        true);
+  m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS",
+                         c.is_quant ? KH_WG : KH_WG_MAX, KH_WG_MAX);
   m->nparts = m->sh_cls.grid;
   m->n_sync = c.layer_num * (c.kv_head_num + KH_SYNC_REPL) * KH_SYNC_STRIDE;
   KH_CHECK_HIP(hipMalloc((void**)&m->sync_words, sizeof(int) * (size_t)(m->n_sync + 1)));
@@ -751,11 +781,17 @@ int finish_create(kh_model* m) {
     const int ppw = KH_WAVES_PER_WG / m->sh_qkv.split;
     const bool aligned = ((c.kv_mul * c.head_size / 2) % 4 == 0) && ((c.head_size / 2) % 4 == 0) &&
                          ((c.kv_mul * c.head_size / 2 + c.head_size) % ppw == 0);
-    if (!off && c.head_size > 32 && kh_stage_maxv(c.dim) == 4 && aligned)
+    if (!off && c.head_size > 32 && kh_stage_maxv(c.dim) == 4 && aligned &&
+        m->sh_qkv.wg == KH_WG && m->sh_wo.wg == KH_WG)
       m->merge_combo = merged_combo_id(c.is_quant, m->sh_qkv.u, m->sh_qkv.split,
                                        attn_group_lanes(c), m->sh_wo.u, m->sh_wo.split);
   }
   m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
+  // attention: 8 waves per (head, split) shorten each lane's timestep loop; the merged launch
+  // shares its workgroup size with qkv/wo
+  m->attn_wg = m->merge_combo >= 0 ? KH_WG : KH_WG_MAX;
+  if (const char* e = getenv("KH_ATTN_WG"))
+    if (m->merge_combo < 0 && (atoi(e) == 256 || atoi(e) == 512)) m->attn_wg = atoi(e);
   if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ns)) {
     KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
     KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));

@@ -165,7 +165,13 @@ def test_merged_launch_equals_three_launches(gpu, preset):
     spec = binfmt.PRESETS[preset]
     img_d, _ = _synth(spec, 4321, gpu)
     a = KuiperModel.from_device_image(img_d, spec, max_seq_len=512, flags=KH_FLAG_MERGE)
-    b = KuiperModel.from_device_image(img_d, spec, max_seq_len=512)
+    # the merged launch runs attention with 256-thread workgroups (shared with qkv/wo); give
+    # the stand-alone attention kernel the same width so the summation order is the same
+    os.environ["KH_ATTN_WG"] = "256"
+    try:
+        b = KuiperModel.from_device_image(img_d, spec, max_seq_len=512)
+    finally:
+        del os.environ["KH_ATTN_WG"]
     assert a.cfg.merged_launch == 1 and b.cfg.merged_launch == 0
     assert a.cfg.launches_per_token == 3 * spec.n_layers + 2
     for mode in ("graph", "fused"):
