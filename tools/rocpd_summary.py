@@ -47,7 +47,7 @@ def main():
         rows = db.execute(
             "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
             "max(grid_x), max(workgroup_x), max(vgpr_count), max(lds_size) "
-            "from kernels group by name").fetchall()
+            "from kernels group by name, grid_x, workgroup_x").fetchall()
         mine = [r for r in rows if ours(r[0])]
         tot = sum(r[2] for r in mine)
         p = os.path.join(out, f"{a.round}_kernel_stats.csv")

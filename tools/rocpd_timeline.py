@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 db = sqlite3.connect(sys.argv[1])
-rows = db.execute("select name, start, end, grid_x, lds_size from kernels order by start").fetchall()
+rows = db.execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
 def short(n):
     n = re.sub(r"^void ", "", n)
     return re.sub(r"\(.*$", "", n)
@@ -16,7 +16,7 @@ ours = [(short(n), s, e, g, l) for (n, s, e, g, l) in rows if re.match(r"^(void 
 dur = defaultdict(list)
 gap = defaultdict(list)
 for i, (n, s, e, g, l) in enumerate(ours):
-    key = f"{n} grid={g // 256}"
+    key = f"{n} grid={g // max(l, 1)}x{l}"
     dur[key].append((e - s) / 1e3)
     if i + 1 < len(ours):
         gp = (ours[i + 1][1] - e) / 1e3
