@@ -104,11 +104,14 @@ int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num, int32_t laye
                float* mha_out, const float* q, float* score, const float* kcache,
                const float* vcache, void* stream);
 
-/* The decode-path attention kernel with its long-context time split: the grid carries
- * ceil(seq_len/1024) (<= 16) workgroups per head; positions < 256 use one of them, longer
+/* The decode-path attention kernel with its long-context machinery.  Per-head path: the grid
+ * carries ceil(seq_len/256) (<= 16) workgroups per head; positions < 256 use one of them, longer
  * contexts split the timesteps and the last workgroup to finish merges the partial
- * (max, sum, o) triples.  `workspace` = kh_mha_decode_workspace_bytes(...) bytes, 16-byte
- * aligned, ZEROED once before first use (the kernel re-arms it); may be NULL when that is 0. */
+ * (max, sum, o) triples.  GQA models (kv_mul 2/4/7/8) switch, from pos + 1 >= 4096 on
+ * (env KH_ATTN_TLONG; 0 = never), to one workgroup per (kv group, time split) that computes the
+ * group's kv_mul heads from ONE pass over the K/V rows.  `workspace` =
+ * kh_mha_decode_workspace_bytes(...) bytes, 16-byte aligned, ZEROED once before first use (the
+ * kernel re-arms it); may be NULL when that is 0. */
 int64_t kh_mha_decode_workspace_bytes(int32_t head_num, int32_t head_size, int32_t seq_len);
 int kh_mha_decode_f32(const int32_t* d_pos, int32_t pos, int32_t head_num, int32_t layer_index,
                       int32_t seq_len, int32_t kv_dim, int32_t kv_mul, int32_t head_size,
@@ -217,8 +220,9 @@ int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prom
                             float* h_elapsed_ms);
 
 /* Average duration of ONE kernel class launched back to back (no event between launches, so
- * no event overhead in the figure): the kernel is enqueued for layers 0..L-1 `reps` times
- * between two HIP events on the model stream (cls / sample: `reps` launches); consecutive
+ * no event overhead in the figure): the kernel is captured for layers 0..L-1 `reps` times into
+ * a hipGraph that is replayed between two HIP events on the model stream (cls / sample: `reps`
+ * launches; a graph because a 3-4 us kernel outruns eager host enqueues); consecutive
  * launches read different layers' weights, so nothing is served from cache.  This is the
  * number bench.py's roofline uses and the one rocprofv3's per-kernel average must agree with.
  * Destroys the activation state and KV row `pos` (a later generate/predict resets both). */

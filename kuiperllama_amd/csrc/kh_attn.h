@@ -132,8 +132,9 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
   if (tid < hs) {
     float r = 0.f;
     // when G == 256/TPI... every wave holds a partial for every d (TPI >= 4 <=> G <= 64)
+    const int nw = kh_nwaves();
 #pragma unroll
-    for (int w = 0, nw = kh_nwaves(); w < nw; ++w) r += opart[w * hs + tid];
+    for (int w = 0; w < KH_WAVES_MAX; ++w) r += w < nw ? opart[(w < nw ? w : 0) * hs + tid] : 0.f;
     out_h[tid] = single ? r : r / l_run;
   }
   if (score_out) {
@@ -164,14 +165,19 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 // placement-independent (splits of a head land on different XCDs) and never waits on another
 // workgroup, so it cannot hang.  The ticket counter is re-armed by the merger.
 #define KH_ATTN_UB 4
+#ifndef KH_ATTN_MIN_TS
 #define KH_ATTN_MIN_TS 256  // timesteps per split before a second split is opened
+#endif
 #define KH_ATTN_MAX_NS 16
+#define KH_ATTN_TLONG_DEFAULT 4096  // pos + 1 from which GQA models switch to the group path
+#define KH_ATTN_MAX_NS_G 32          // splits per KV group (the last arriver merges them all)
+#define KH_ATTN_MIN_GROUPS 4         // fewer KV heads than this: too few workgroups, stay per-head
 static inline size_t attn_fast_lds_bytes(int head_size, int wg = KH_WG) {
   return (size_t)(8 + 8 + (wg / KH_WAVE) * head_size) * sizeof(float);
 }
 // splits per head carried by the grid for a cache of `cache_len` rows
 static inline int attn_num_splits(int cache_len) {
-  int ns = (cache_len + 1023) / 1024;
+  int ns = (cache_len + KH_ATTN_MIN_TS - 1) / KH_ATTN_MIN_TS;
   if (ns < 1) ns = 1;
   if (ns > KH_ATTN_MAX_NS) ns = KH_ATTN_MAX_NS;
   return ns;
@@ -289,7 +295,10 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   float mw = across_groups_max<G>(m);
   if (lane == 0) red[wave] = mw;
   __syncthreads();
-  const float M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float M = red[0];
+  const int nw = kh_nwaves();
+#pragma unroll
+  for (int w = 1; w < KH_WAVES_MAX; ++w) M = fmaxf(M, red[w < nw ? w : 0]);
   const float f = expf(m - M);  // groups that saw no timestep have m = -inf -> 0
   l = across_groups_sum<G>(l * f);
   o.x = across_groups_sum<G>(o.x * f);
@@ -301,14 +310,58 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   __syncthreads();
   float r = 0.f, L = 0.f;
   if (tid < hs) {
-    for (int w = 0, nw = kh_nwaves(); w < nw; ++w) {
-      r += opart[w * hs + tid];
-      L += lpart[w];
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_MAX; ++w) {
+      const int wc = w < nw ? w : 0;
+      r += w < nw ? opart[wc * hs + tid] : 0.f;
+      L += w < nw ? lpart[wc] : 0.f;
     }
   }
   r_out = r;
   L_out = L;
   return M;
+}
+
+// Merge of the nact split partials of head h, element e (last arriver only).  The partials were
+// written by other workgroups: agent-scope relaxed atomic loads (vector path to L2, never a
+// stale L1 / scalar-cache line).  Loads are issued in batches of KH_ATTN_MB before any is
+// used, so the merge costs nact/KH_ATTN_MB memory round trips instead of nact.
+#define KH_ATTN_MB 16
+__device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h, int e, int hs,
+                                                   int nact, int NSW) {
+  const size_t base = (size_t)h * NSW;
+  float Mx = -INFINITY;
+  for (int k0 = 0; k0 < nact; k0 += KH_ATTN_MB) {
+    float mv[KH_ATTN_MB];
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_MB; ++u) {
+      const int k = k0 + u < nact ? k0 + u : nact - 1;
+      mv[u] = __hip_atomic_load(&ws.ml[(base + k) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_MB; ++u) Mx = fmaxf(Mx, mv[u]);
+  }
+  float num = 0.f, den = 0.f;
+  for (int k0 = 0; k0 < nact; k0 += KH_ATTN_MB) {
+    float mv[KH_ATTN_MB], lv[KH_ATTN_MB], ov[KH_ATTN_MB];
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_MB; ++u) {
+      const int k = k0 + u < nact ? k0 + u : nact - 1;
+      const size_t sl = base + k;
+      mv[u] = __hip_atomic_load(&ws.ml[sl * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lv[u] = __hip_atomic_load(&ws.ml[sl * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ov[u] = __hip_atomic_load(&ws.o[sl * hs + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_MB; ++u) {
+      if (k0 + u < nact) {  // ascending k, one term per split: the order does not depend on MB
+        const float f = expf(mv[u] - Mx);
+        num = __builtin_fmaf(ov[u], f, num);
+        den = __builtin_fmaf(lv[u], f, den);
+      }
+    }
+  }
+  return num / den;
 }
 
 // One workgroup = (head h, split s) of a grid of heads*NS workgroups.  ws may be null iff NS==1.
@@ -319,7 +372,8 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
                                                       const float* v_base, int kv_stride, int hs,
                                                       int pos, float* out_h, float* smem, int h,
                                                       int s, int NS, AttnSplitWs ws,
-                                                      WaitFn&& WAIT = WaitFn()) {
+                                                      WaitFn&& WAIT = WaitFn(), int NSW = 0) {
+  if (NSW <= 0) NSW = NS;  // slot stride of the workspace (>= NS)
   const int tid = threadIdx.x;
   const int nT = pos + 1;
   const int TS = attn_split_len(nT, NS);
@@ -340,7 +394,7 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
     return true;
   }
   // ---- publish this split's partial, take a ticket ---------------------------------------
-  const size_t slot = (size_t)h * NS + s;
+  const size_t slot = (size_t)h * NSW + s;
   if (tid < hs) ws.o[slot * hs + tid] = r;
   if (tid == 0) {
     ws.ml[slot * 2] = M;
@@ -360,28 +414,299 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
   if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
   if (tid < hs) {
-    // agent-scope relaxed atomic loads: vector path to L2, never the scalar cache
-    float Mx = -INFINITY;
-    for (int k = 0; k < nact; ++k)
-      Mx = fmaxf(Mx, __hip_atomic_load(&ws.ml[((size_t)h * NS + k) * 2], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT));
-    float num = 0.f, den = 0.f;
-    for (int k = 0; k < nact; ++k) {
-      const size_t sl = (size_t)h * NS + k;
-      const float Mk = __hip_atomic_load(&ws.ml[sl * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float Lk =
-          __hip_atomic_load(&ws.ml[sl * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float ok =
-          __hip_atomic_load(&ws.o[sl * hs + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float f = expf(Mk - Mx);
-      num = __builtin_fmaf(ok, f, num);
-      den = __builtin_fmaf(Lk, f, den);
-    }
+    const float v = attn_merge_splits(ws, h, tid, hs, nact, NSW);
     if (SC1)
-      st_sc1(out_h + tid, num / den);
+      st_sc1(out_h + tid, v);
     else
-      out_h[tid] = num / den;
+      out_h[tid] = v;
   }
   if (tid == 0) __hip_atomic_store(&ws.cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
+}
+
+
+// =============================================================================================
+// GQA long-context core.  One workgroup = (kv group g, time split s) computes ALL KVM query
+// heads of the group from ONE pass over the group's K/V rows: at long contexts the per-head
+// kernel re-reads every K/V row kv_mul times (from L2 at best), which is what bounds it
+// (2.6 TB/s of K/V bytes at pos 131071 on Llama-3.2-1B); here every K/V byte crosses the memory
+// system once.  The cost is KVM times the arithmetic per loaded byte, so the softmax runs in the
+// log2 domain on the hardware exp2 (v_exp_f32) and the rescale factor is computed once per
+// batch of KH_ATTN_UB timesteps instead of once per timestep.  Used only when pos + 1 >=
+// t_long (short contexts are latency-bound and prefer one workgroup per head).
+// smem: red[KH_WAVES_MAX*KVM] | lpart[KH_WAVES_MAX*KVM] | opart[KH_WAVES_MAX*KVM*hs]
+static inline size_t attn_group_lds_bytes(int head_size, int kvm) {
+  return (size_t)KH_WAVES_MAX * kvm * (2 + head_size) * sizeof(float);
+}
+// splits per KV group carried by the grid: enough workgroups to cover every CU twice
+static inline int attn_group_splits(int cache_len, int kv_heads) {
+  int ns = (cache_len + KH_ATTN_MIN_TS - 1) / KH_ATTN_MIN_TS;
+  int want = (512 + kv_heads - 1) / kv_heads;
+  if (want > KH_ATTN_MAX_NS_G) want = KH_ATTN_MAX_NS_G;
+  if (ns > want) ns = want;
+  return ns < 1 ? 1 : ns;
+}
+
+template <int G, int KVM>
+__device__ __forceinline__ void attn_group_partial(const float* q_g, const float* k_base,
+                                                   const float* v_base, int kv_stride, int hs,
+                                                   int t_begin, int t_end, float* smem,
+                                                   float& r_out, float& L_out, float& M_out) {
+  static_assert(G == 16 || G == 32 || G == 64, "G must be 16, 32 or 64");
+  const int TPI = kh_wg() / G;
+  const int nw = kh_nwaves();
+  float* red = smem;
+  float* lpart = red + KH_WAVES_MAX * KVM;
+  float* opart = lpart + KH_WAVES_MAX * KVM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tg = tid / G, dl = tid - tg * G;
+  const int hs4 = hs >> 2;
+  const bool active = dl < hs4;
+  const int stride4 = kv_stride >> 2;
+  const f32x4* K4 = (const f32x4*)k_base;
+  const f32x4* V4 = (const f32x4*)v_base;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const float sc2 = 1.4426950408889634f / sqrtf((float)hs);  // scores in the log2 domain
+  f32x4 q4[KVM], o[KVM];
+  float m[KVM], l[KVM];
+#pragma unroll
+  for (int j = 0; j < KVM; ++j) {
+    q4[j] = active ? ((const f32x4*)(q_g + (size_t)j * hs))[dl] : zero4;
+    o[j] = zero4;
+    m[j] = -INFINITY;
+    l[j] = 0.f;
+  }
+  for (int tb = t_begin + tg; tb < t_end; tb += TPI * KH_ATTN_UB) {
+    f32x4 kv[KH_ATTN_UB], vv[KH_ATTN_UB];
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_UB; ++u) {
+      const int t = tb + u * TPI;
+      const int tt = t < t_end ? t : t_end - 1;
+      kv[u] = active ? ld_nt(K4 + (size_t)tt * stride4 + dl) : zero4;
+      vv[u] = active ? ld_nt(V4 + (size_t)tt * stride4 + dl) : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < KVM; ++j) {
+      float sv[KH_ATTN_UB];
+      float mx = m[j];
+#pragma unroll
+      for (int u = 0; u < KH_ATTN_UB; ++u) {
+        sv[u] = group_sum<G>(fma4(q4[j], kv[u], 0.f)) * sc2;  // all lanes: DPP, no branch
+        if (tb + u * TPI < t_end) mx = fmaxf(mx, sv[u]);       // u = 0 is always valid
+      }
+      const float alpha = __builtin_amdgcn_exp2f(m[j] - mx);  // exp2(-inf) = 0 on the first batch
+      float lj = l[j] * alpha;
+      f32x4 oj = o[j] * alpha;
+#pragma unroll
+      for (int u = 0; u < KH_ATTN_UB; ++u) {
+        if (tb + u * TPI < t_end) {
+          const float p = __builtin_amdgcn_exp2f(sv[u] - mx);
+          lj += p;
+          oj.x = __builtin_fmaf(p, vv[u].x, oj.x);
+          oj.y = __builtin_fmaf(p, vv[u].y, oj.y);
+          oj.z = __builtin_fmaf(p, vv[u].z, oj.z);
+          oj.w = __builtin_fmaf(p, vv[u].w, oj.w);
+        }
+      }
+      l[j] = lj;
+      o[j] = oj;
+      m[j] = mx;
+    }
+  }
+  // ---- merge the lane groups of a wave, then the waves -----------------------------------------
+#pragma unroll
+  for (int j = 0; j < KVM; ++j) {
+    const float mw = across_groups_max<G>(m[j]);
+    if (lane == 0) red[wave * KVM + j] = mw;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KVM; ++j) {
+    float M2 = red[j];
+#pragma unroll
+    for (int w = 1; w < KH_WAVES_MAX; ++w) M2 = fmaxf(M2, red[(w < nw ? w : 0) * KVM + j]);
+    const float f = __builtin_amdgcn_exp2f(m[j] - M2);  // groups without a timestep: m = -inf -> 0
+    const float lw = across_groups_sum<G>(l[j] * f);
+    f32x4 ow;
+    ow.x = across_groups_sum<G>(o[j].x * f);
+    ow.y = across_groups_sum<G>(o[j].y * f);
+    ow.z = across_groups_sum<G>(o[j].z * f);
+    ow.w = across_groups_sum<G>(o[j].w * f);
+    if (lane < G && active) ((f32x4*)(opart + (size_t)(wave * KVM + j) * hs))[dl] = ow;
+    if (lane == 0) lpart[wave * KVM + j] = lw;
+  }
+  __syncthreads();
+  float r = 0.f, L = 0.f, M2 = -INFINITY;
+  if (tid < KVM * hs) {
+    const int j = tid / hs, e = tid - j * hs;
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_MAX; ++w) {
+      const int wc = w < nw ? w : 0;
+      r += w < nw ? opart[(size_t)(wc * KVM + j) * hs + e] : 0.f;
+      L += w < nw ? lpart[wc * KVM + j] : 0.f;
+      M2 = fmaxf(M2, red[wc * KVM + j]);
+    }
+  }
+  r_out = r;
+  L_out = L;
+  M_out = M2 * 0.6931471805599453f;  // back to the natural-log domain of the split merge
+}
+
+// One workgroup = (kv group g, split s); heads g*KVM .. g*KVM+KVM-1.  Workspace slots and the
+// merge are those of the per-head path (slot = h*NSW + s); the arrival ticket of the group is
+// the ticket of its first head.  Requires KVM*hs <= blockDim.x.
+template <int G, int KVM>
+__device__ __forceinline__ void attn_group_decode(const float* q_g, const float* k_base,
+                                                  const float* v_base, int kv_stride, int hs,
+                                                  int pos, float* out_g, float* smem, int g, int s,
+                                                  int NS, int NSW, AttnSplitWs ws) {
+  const int tid = threadIdx.x;
+  const int nT = pos + 1;
+  const int TS = attn_split_len(nT, NS);
+  const int nact = (nT + TS - 1) / TS;  // uniform over the grid
+  if (s >= nact) return;
+  const int t_begin = s * TS;
+  const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
+  float r, L, M;
+  attn_group_partial<G, KVM>(q_g, k_base, v_base, kv_stride, hs, t_begin, t_end, smem, r, L, M);
+  const bool mine = tid < KVM * hs;
+  const int j = mine ? tid / hs : 0, e = tid - j * hs;
+  const int h = g * KVM + j;
+  if (nact == 1) {
+    if (mine) out_g[(size_t)j * hs + e] = r / L;
+    return;
+  }
+  const size_t slot = (size_t)h * NSW + s;
+  if (mine) {
+    ws.o[slot * hs + e] = r;
+    if (e == 0) {
+      ws.ml[slot * 2] = M;
+      ws.ml[slot * 2 + 1] = L;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+  __syncthreads();
+  int* flag = (int*)smem;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    flag[0] = __hip_atomic_fetch_add(&ws.cnt[g * KVM], 1, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (flag[0] != nact - 1) return;  // not the last arriver
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  if (mine) out_g[(size_t)j * hs + e] = attn_merge_splits(ws, h, e, hs, nact, NSW);
+  if (tid == 0)
+    __hip_atomic_store(&ws.cnt[g * KVM], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// =============================================================================================
+// The decode-attention launch shared by the fused step (kh_model.hip) and the operator-level
+// entry point kh_mha_decode_f32 (kh_ops.hip).
+struct KhAttnArgs {
+  const float* q;          // [dim]
+  const float* kcache_layer;
+  const float* vcache_layer;
+  float* out;              // [dim]
+  const int32_t* d_pos;
+  int kv_dim, kv_mul, head_size;
+  int kv_heads, nsplit;    // per-head path: kv_heads * kv_mul * nsplit workgroups
+  void* ws;                // attn_ws_bytes(heads, head_size, ws_stride), tickets zeroed
+  int ws_stride;           // split slots per head in the workspace (>= nsplit, >= nsplit_g)
+  int nsplit_g;            // GQA long-context path: kv_heads * nsplit_g workgroups (0 = off)
+  int t_long;              // the group path runs when pos + 1 >= t_long
+};
+
+// per-head path: block -> (kv group g, head-in-group j, split s).  Blocks are placed on XCD
+// b % 8, so with g = b % kv_heads the kv_mul heads that share K/V rows share an XCD's L2.
+template <int G>
+__device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem, int b, int pos) {
+  const int g = b % a.kv_heads;
+  const int j = (b / a.kv_heads) % a.kv_mul;
+  const int s = b / (a.kv_heads * a.kv_mul);
+  const int h = g * a.kv_mul + j;
+  const size_t head_off = (size_t)g * a.head_size;
+  attn_head_decode_fast<G, false>(
+      a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
+      a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, smem, h, s, a.nsplit,
+      attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), AttnNoWait{},
+      a.ws_stride);
+}
+
+// KVM = 0: per-head workgroups only.  KVM = kv_mul > 1: per-head workgroups at short contexts,
+// one workgroup per (kv group, split) computing the group's KVM heads from one pass over K/V
+// once pos + 1 >= t_long.  The choice is uniform over the grid (it depends on the position
+// only), so one captured launch serves every position; workgroups beyond the active path's
+// count leave immediately.
+template <int G, int KVM>
+__global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(const KhAttnArgs a, int host_pos) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int pos = a.d_pos ? *a.d_pos : host_pos;
+  const int b = (int)blockIdx.x;
+  if (KVM == 0 || pos + 1 < a.t_long) {
+    if (b < a.kv_heads * a.kv_mul * a.nsplit) attn_head_block<G>(a, (float*)smem_raw, b, pos);
+    return;
+  }
+  if constexpr (KVM > 0) {
+    if (b >= a.kv_heads * a.nsplit_g) return;
+    const int g = b % a.kv_heads, s = b / a.kv_heads;
+    const size_t head_off = (size_t)g * a.head_size;
+    attn_group_decode<G, KVM>(a.q + (size_t)g * KVM * a.head_size, a.kcache_layer + head_off,
+                              a.vcache_layer + head_off, a.kv_dim, a.head_size, pos,
+                              a.out + (size_t)g * KVM * a.head_size, (float*)smem_raw, g, s,
+                              a.nsplit_g, a.ws_stride,
+                              attn_ws_carve(a.ws, a.kv_heads * KVM, a.head_size, a.ws_stride));
+  }
+}
+
+// lanes cooperating on one timestep for this head size
+static inline int attn_lanes(int head_size) {
+  int G = 1;
+  while (G < head_size / 4) G <<= 1;
+  return G < 16 ? 16 : G;
+}
+// is the GQA group path instantiated for this geometry (and does it fit a `wg`-thread workgroup)?
+static inline bool attn_group_supported(int head_size, int kv_mul, int wg) {
+  const int G = attn_lanes(head_size);
+  if (kv_mul * head_size > wg) return false;
+  if (G == 16) return kv_mul == 2 || kv_mul == 4 || kv_mul == 7 || kv_mul == 8;
+  if (G == 32) return kv_mul == 2 || kv_mul == 4;
+  return false;
+}
+// Launch.  a.nsplit_g == 0 disables the group path; head_size > 32 required (callers route
+// smaller heads to the generic LDS-score kernel).
+static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStream_t s) {
+  const int G = attn_lanes(a.head_size);
+  const bool grp = a.nsplit_g > 0 && attn_group_supported(a.head_size, a.kv_mul, wg);
+  if (!grp) a.nsplit_g = 0;
+  int grid = a.kv_heads * a.kv_mul * a.nsplit;
+  size_t lds = attn_fast_lds_bytes(a.head_size, wg);
+  if (grp) {
+    if (a.kv_heads * a.nsplit_g > grid) grid = a.kv_heads * a.nsplit_g;
+    const size_t l2 = attn_group_lds_bytes(a.head_size, a.kv_mul);
+    if (l2 > lds) lds = l2;
+  }
+#define KH_ATTN_LAUNCH(GG, KK) \
+  hipLaunchKernelGGL((k_attn_decode<GG, KK>), dim3(grid), dim3(wg), lds, s, a, host_pos)
+  const int kvm = grp ? a.kv_mul : 0;
+  if (G == 16) {
+    switch (kvm) {
+      case 2: KH_ATTN_LAUNCH(16, 2); break;
+      case 4: KH_ATTN_LAUNCH(16, 4); break;
+      case 7: KH_ATTN_LAUNCH(16, 7); break;
+      case 8: KH_ATTN_LAUNCH(16, 8); break;
+      default: KH_ATTN_LAUNCH(16, 0); break;
+    }
+  } else if (G == 32) {
+    switch (kvm) {
+      case 2: KH_ATTN_LAUNCH(32, 2); break;
+      case 4: KH_ATTN_LAUNCH(32, 4); break;
+      default: KH_ATTN_LAUNCH(32, 0); break;
+    }
+  } else {
+    KH_ATTN_LAUNCH(64, 0);
+  }
+#undef KH_ATTN_LAUNCH
 }

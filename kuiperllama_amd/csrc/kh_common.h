@@ -196,7 +196,9 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   if (lane == 0) red[wave] = v;
   __syncthreads();
   float r = 0.f;
-  for (int w = 0, n = kh_nwaves(); w < n; ++w) r += red[w];
+  const int n = kh_nwaves();
+#pragma unroll  // clamped index + select: all KH_WAVES_MAX LDS reads issue back to back
+  for (int w = 0; w < KH_WAVES_MAX; ++w) r += w < n ? red[w < n ? w : 0] : 0.f;
   __syncthreads();
   return r;
 }
@@ -206,7 +208,9 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   if (lane == 0) red[wave] = v;
   __syncthreads();
   float r = red[0];
-  for (int w = 1, n = kh_nwaves(); w < n; ++w) r = fmaxf(r, red[w]);
+  const int n = kh_nwaves();
+#pragma unroll
+  for (int w = 1; w < KH_WAVES_MAX; ++w) r = fmaxf(r, red[w < n ? w : 0]);
   __syncthreads();
   return r;
 }

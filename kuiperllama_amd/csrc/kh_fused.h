@@ -202,16 +202,6 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-struct KhAttnArgs {
-  const float* q;          // [dim]
-  const float* kcache_layer;
-  const float* vcache_layer;
-  float* out;              // [dim]
-  const int32_t* d_pos;
-  int kv_dim, kv_mul, head_size;
-  int kv_heads, nsplit;    // grid = kv_heads * kv_mul * nsplit workgroups
-  void* ws;                // attn_ws_bytes(heads, head_size, nsplit), tickets zeroed
-};
 template <int G, bool MERGED>
 __device__ __forceinline__ void attn_body(const KhAttnArgs& a, char* smem_raw, int b,
                                           const KhSync& sync) {
@@ -240,7 +230,8 @@ __device__ __forceinline__ void attn_body(const KhAttnArgs& a, char* smem_raw, i
   const bool wrote = attn_head_decode_fast<G, MERGED>(
       a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
       a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, (float*)smem_raw, h, s,
-      a.nsplit, attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.nsplit), wait);
+      a.nsplit, attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), wait,
+      a.ws_stride);
   if (MERGED && wrote) {  // uniform per workgroup: one arrival on every replica
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -249,12 +240,6 @@ __device__ __forceinline__ void attn_body(const KhAttnArgs& a, char* smem_raw, i
                              __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-template <int G>
-__global__ __launch_bounds__(KH_WG_MAX) void k_attn(const KhAttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  attn_body<G, false>(a, smem_raw, (int)blockIdx.x, KhSync{});
-}
-
 // head_size <= 32 (tiny test models): the generic LDS-score core of the op-level kernel
 __global__ __launch_bounds__(KH_WG_MAX) void k_attn_generic(const KhAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

@@ -58,6 +58,9 @@ struct kh_model {
   int merge_combo = -1;       // kh_merged.h combination id, -1 = stand-alone kernels
   void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
   int attn_ns = 1;
+  int attn_ns_g = 0;        // GQA long-context path: splits per KV group (0 = path off)
+  int attn_ws_stride = 1;   // split slots per head in attn_ws
+  int attn_t_long = 1 << 30;
   int attn_wg = KH_WG;
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
@@ -260,6 +263,9 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   a.kv_heads = c.kv_head_num;
   a.nsplit = m->attn_ns;
   a.ws = m->attn_ws;
+  a.ws_stride = m->attn_ws_stride;
+  a.nsplit_g = m->attn_ns_g;
+  a.t_long = m->attn_t_long;
   return a;
 }
 int attn_group_lanes(const kh_config& c) {
@@ -270,17 +276,9 @@ int attn_group_lanes(const kh_config& c) {
 void launch_attn(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const KhAttnArgs a = fill_attn(m, l);
-  int G = 1;
-  while (G < c.head_size / 4) G <<= 1;
   const int wg = m->attn_wg;
-  const size_t lds = attn_fast_lds_bytes(c.head_size, wg);
-  const dim3 grid(c.head_num * m->attn_ns);
-  if (G <= 16 && c.head_size > 32)
-    hipLaunchKernelGGL(k_attn<16>, grid, dim3(wg), lds, m->stream, a);
-  else if (G == 32)
-    hipLaunchKernelGGL(k_attn<32>, grid, dim3(wg), lds, m->stream, a);
-  else if (G == 64)
-    hipLaunchKernelGGL(k_attn<64>, grid, dim3(wg), lds, m->stream, a);
+  if (c.head_size > 32)
+    launch_attn_decode(a, 0, wg, m->stream);
   else  // head_size <= 32: generic LDS-score kernel (tiny test models)
     hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(wg),
                        attn_lds_bytes(c.head_size, wg), m->stream, a);
@@ -792,7 +790,22 @@ int finish_create(kh_model* m) {
   m->attn_wg = m->merge_combo >= 0 ? KH_WG : KH_WG_MAX;
   if (const char* e = getenv("KH_ATTN_WG"))
     if (m->merge_combo < 0 && (atoi(e) == 256 || atoi(e) == 512)) m->attn_wg = atoi(e);
-  if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ns)) {
+  // GQA long-context path (kh_attn.h): one workgroup per (kv group, split) from pos + 1 >=
+  // t_long on; KH_ATTN_TLONG overrides the threshold (0 = never)
+  m->attn_ws_stride = m->attn_ns;
+  if (c.kv_mul > 1 && c.head_size > 32 && m->merge_combo < 0 &&
+      attn_group_supported(c.head_size, c.kv_mul, m->attn_wg)) {
+    // default policy: models with few KV heads (Qwen2.5-0.5B: 2) cannot fill the chip with
+    // (group, split) workgroups and stay per-head; an explicit KH_ATTN_TLONG overrides
+    int t_long = c.kv_head_num >= KH_ATTN_MIN_GROUPS ? KH_ATTN_TLONG_DEFAULT : 0;
+    if (const char* e = getenv("KH_ATTN_TLONG")) t_long = atoi(e);
+    if (t_long > 0 && t_long <= (int)c.cache_len) {
+      m->attn_ns_g = attn_group_splits(c.cache_len, c.kv_head_num);
+      m->attn_t_long = t_long;
+      if (m->attn_ns_g > m->attn_ws_stride) m->attn_ws_stride = m->attn_ns_g;
+    }
+  }
+  if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride)) {
     KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
     KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));
   }
@@ -1202,12 +1215,29 @@ extern "C" int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos,
         default: launch_sample(m, /*advance=*/0, /*n_forced=*/0); break;
       }
   };
-  sweep();  // untimed: first-touch effects
-  KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+  // The sweeps are captured into a graph and replayed: a 3-4 us kernel finishes faster than the
+  // host can enqueue the next one, so eager back-to-back launches would time the host.
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  KH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
   for (int r = 0; r < reps; ++r) sweep();
-  KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
-  KH_CHECK_HIP(hipEventSynchronize(m->ev1));
-  int rc = kh_launch_status();
+  hipError_t e = hipStreamEndCapture(m->stream, &g);
+  if (e != hipSuccess) return (int)e;
+  e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    return (int)e;
+  }
+  int rc = KH_OK;
+  e = hipGraphLaunch(ge, m->stream);  // untimed: first-touch effects
+  if (e == hipSuccess) e = hipEventRecord(m->ev0, m->stream);
+  if (e == hipSuccess) e = hipGraphLaunch(ge, m->stream);
+  if (e == hipSuccess) e = hipEventRecord(m->ev1, m->stream);
+  if (e == hipSuccess) e = hipEventSynchronize(m->ev1);
+  (void)hipGraphExecDestroy(ge);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return (int)e;
+  rc = kh_launch_status();
   if (rc != KH_OK) return rc;
   float ms = 0.f;
   KH_CHECK_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));

@@ -427,49 +427,29 @@ __global__ __launch_bounds__(KH_WG) void k_mha(const int32_t* __restrict__ d_pos
                    (float*)smem_raw);
 }
 
-template <int G>
-__global__ __launch_bounds__(KH_WG) void k_mha_fast(const int32_t* __restrict__ d_pos, int pos_val,
-                                                    int layer_index, int seq_len, int kv_dim,
-                                                    int kv_mul, int head_size, int head_num,
-                                                    int nsplit, void* ws,
-                                                    float* __restrict__ mha_out,
-                                                    const float* __restrict__ q,
-                                                    const float* __restrict__ kcache,
-                                                    const float* __restrict__ vcache) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int pos = d_pos ? *d_pos : pos_val;
-  const int kv_heads = head_num / kv_mul;
-  const int b = blockIdx.x;
-  const int g = b % kv_heads;
-  const int j = (b / kv_heads) % kv_mul;
-  const int s = b / head_num;
-  const int h = g * kv_mul + j;
-  const size_t layer_off = (size_t)layer_index * (size_t)seq_len * (size_t)kv_dim;
-  const size_t head_off = (size_t)g * head_size;
-  attn_head_decode_fast<G>(q + (size_t)h * head_size, kcache + layer_off + head_off,
-                           vcache + layer_off + head_off, kv_dim, head_size, pos,
-                           mha_out + (size_t)h * head_size, (float*)smem_raw, h, s, nsplit,
-                           attn_ws_carve(ws, head_num, head_size, nsplit));
-}
-
+// decode attention through the launch the fused step uses (kh_attn.h); ns_g == 0: per-head only
 static int launch_mha_fast(const int32_t* d_pos, int32_t pos, int32_t head_num,
                            int32_t layer_index, int32_t seq_len, int32_t kv_dim, int32_t kv_mul,
                            int32_t head_size, float* mha_out, const float* q, const float* kcache,
-                           const float* vcache, int nsplit, void* ws, hipStream_t s) {
-  int G = 1;
-  while (G < head_size / 4) G <<= 1;
-  const size_t lds = attn_fast_lds_bytes(head_size);
-#define KH_MHA_FAST(GG)                                                                        \
-  hipLaunchKernelGGL(k_mha_fast<GG>, dim3(head_num * nsplit), dim3(KH_WG), lds, s, d_pos, pos, \
-                     layer_index, seq_len, kv_dim, kv_mul, head_size, head_num, nsplit, ws,    \
-                     mha_out, q, kcache, vcache)
-  if (G <= 16)
-    KH_MHA_FAST(16);
-  else if (G == 32)
-    KH_MHA_FAST(32);
-  else
-    KH_MHA_FAST(64);
-#undef KH_MHA_FAST
+                           const float* vcache, int nsplit, int nsplit_g, int ws_stride,
+                           int t_long, void* ws, hipStream_t s) {
+  const size_t layer_off = (size_t)layer_index * (size_t)seq_len * (size_t)kv_dim;
+  KhAttnArgs a;
+  a.q = q;
+  a.kcache_layer = kcache + layer_off;
+  a.vcache_layer = vcache + layer_off;
+  a.out = mha_out;
+  a.d_pos = d_pos;
+  a.kv_dim = kv_dim;
+  a.kv_mul = kv_mul;
+  a.head_size = head_size;
+  a.kv_heads = head_num / kv_mul;
+  a.nsplit = nsplit;
+  a.ws = ws;
+  a.ws_stride = ws_stride;
+  a.nsplit_g = nsplit_g;
+  a.t_long = t_long;
+  launch_attn_decode(a, pos, KH_WG_MAX, s);
   return kh_launch_status();
 }
 
@@ -488,7 +468,7 @@ extern "C" int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
     // no score tensor requested: the fused decode path's one-round-trip kernel (kh_attn.h),
     // one workgroup per head (kh_mha_decode_f32 adds the long-context time split)
     return launch_mha_fast(d_pos, pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
-                           mha_out, q, kcache, vcache, 1, nullptr, s);
+                           mha_out, q, kcache, vcache, 1, 0, 1, 1 << 30, nullptr, s);
   hipLaunchKernelGGL(k_mha, dim3(head_num), dim3(KH_WG), attn_lds_bytes(head_size), s, d_pos,
                      pos, layer_index, seq_len, kv_dim, kv_mul, head_size, mha_out, q, score,
                      kcache, vcache);
@@ -496,30 +476,64 @@ extern "C" int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
 }
 
 // Decode attention with the long-context time split (the kernel the fused step launches).
+// Split geometry of the decode launch for a cache of seq_len rows (mirrors kh_model.hip).
+static void mha_decode_geometry(int head_num, int kv_mul, int head_size, int seq_len, int* ns,
+                                int* ns_g, int* stride, int* t_long) {
+  *ns = head_size > 32 ? attn_num_splits(seq_len) : 1;
+  *ns_g = 0;
+  *stride = *ns;
+  *t_long = 1 << 30;
+  if (kv_mul > 1 && head_size > 32 && head_num % kv_mul == 0 &&
+      attn_group_supported(head_size, kv_mul, KH_WG_MAX)) {
+    int tl = head_num / kv_mul >= KH_ATTN_MIN_GROUPS ? KH_ATTN_TLONG_DEFAULT : 0;
+    if (const char* e = getenv("KH_ATTN_TLONG")) tl = atoi(e);
+    if (tl > 0 && tl <= seq_len) {
+      *ns_g = attn_group_splits(seq_len, head_num / kv_mul);
+      *t_long = tl;
+      if (*ns_g > *stride) *stride = *ns_g;
+    }
+  }
+}
+static int64_t mha_decode_workspace_bytes_for(int32_t head_num, int32_t kv_mul, int32_t head_size,
+                                              int32_t seq_len) {
+  if (head_num <= 0 || head_size <= 0 || seq_len <= 0 || kv_mul <= 0) return KH_ERR_INVALID_ARG;
+  int ns, ns_g, stride, tl;
+  mha_decode_geometry(head_num, kv_mul, head_size, seq_len, &ns, &ns_g, &stride, &tl);
+  return (int64_t)attn_ws_bytes(head_num, head_size, stride);
+}
 extern "C" int64_t kh_mha_decode_workspace_bytes(int32_t head_num, int32_t head_size,
                                                  int32_t seq_len) {
+  // kv_mul unknown: size for the widest slot stride any geometry can ask for
   if (head_num <= 0 || head_size <= 0 || seq_len <= 0) return KH_ERR_INVALID_ARG;
-  const int ns = head_size > 32 ? attn_num_splits(seq_len) : 1;
-  return (int64_t)attn_ws_bytes(head_num, head_size, ns);
+  int64_t best = 0;
+  for (int kvm : {1, 2, 4, 7, 8})
+    if (head_num % kvm == 0) {
+      const int64_t b = mha_decode_workspace_bytes_for(head_num, kvm, head_size, seq_len);
+      if (b > best) best = b;
+    }
+  return best;
 }
 extern "C" int kh_mha_decode_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
                                  int32_t layer_index, int32_t seq_len, int32_t kv_dim,
                                  int32_t kv_mul, int32_t head_size, float* mha_out, const float* q,
                                  const float* kcache, const float* vcache, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
-  const int ns = head_size > 32 ? attn_num_splits(seq_len) : 1;
   if (head_size <= 32 || kv_mul <= 0 || head_num % kv_mul)
     return kh_mha_f32(d_pos, pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
                       mha_out, q, nullptr, kcache, vcache, stream);
+  int ns, ns_g, stride, tl;
+  mha_decode_geometry(head_num, kv_mul, head_size, seq_len, &ns, &ns_g, &stride, &tl);
   if (!mha_out || !q || !kcache || !vcache || head_num <= 0 || layer_index < 0 || seq_len <= 0 ||
       kv_dim <= 0 || head_size % 4 || head_size > 256 || kv_dim % 4 ||
       (!d_pos && (pos < 0 || pos >= seq_len)) || !kh_aligned16(q) || !kh_aligned16(kcache) ||
       !kh_aligned16(vcache) || !kh_aligned16(mha_out) ||
-      (ns > 1 && (!workspace || workspace_bytes < (int64_t)attn_ws_bytes(head_num, head_size, ns) ||
-                  !kh_aligned16(workspace))))
+      (stride > 1 &&
+       (!workspace || workspace_bytes < (int64_t)attn_ws_bytes(head_num, head_size, stride) ||
+        !kh_aligned16(workspace))))
     return KH_ERR_INVALID_ARG;
   return launch_mha_fast(d_pos, pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
-                         mha_out, q, kcache, vcache, ns, workspace, (hipStream_t)stream);
+                         mha_out, q, kcache, vcache, ns, ns_g, stride, tl, workspace,
+                         (hipStream_t)stream);
 }
 
 // =============================================================================================

@@ -203,6 +203,16 @@ def test_long_generate_crosses_attention_splits(gpu, oracle):
     got2, _ = m.generate([1, 2, 3], steps, exec="fused")
     assert got2 == want
     m.close()
+    # the same run with the GQA group path (one workgroup per kv group and split, kh_attn.h)
+    # switched on from position 300: the captured launch changes path inside the replay
+    os.environ["KH_ATTN_TLONG"] = "300"
+    try:
+        m2 = KuiperModel.from_device_image(img_d, spec)
+    finally:
+        del os.environ["KH_ATTN_TLONG"]
+    got3, _ = m2.generate([1, 2, 3], steps, exec="graph")
+    assert got3 == want, next(i for i, (a, b) in enumerate(zip(got3, want)) if a != b)
+    m2.close()
 
 
 def test_loader_entry_points_agree(gpu):

@@ -326,6 +326,39 @@ def test_mha_decode_time_split(gpu, oracle):
         assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
 
 
+@pytest.mark.parametrize("heads,kv_heads,hs", [(8, 2, 64), (14, 2, 64), (16, 2, 64), (4, 2, 64),
+                                               (8, 2, 128), (4, 2, 128)])
+def test_mha_decode_gqa_group_path(gpu, oracle, heads, kv_heads, hs, monkeypatch):
+    """GQA long-context path: from pos + 1 >= t_long one workgroup per (kv group, split) computes
+    the group's kv_mul heads from one pass over K/V (log2-domain online softmax, hardware exp2).
+    Threshold lowered to 300 so both sides of the switch, the split transitions of the group
+    grid, a spiked key and ticket re-arming are covered at test-sized caches."""
+    from kuiperllama_amd import ops
+    monkeypatch.setenv("KH_ATTN_TLONG", "300")
+    seq = 3000
+    rng = np.random.default_rng(heads * 1000 + hs)
+    kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+    kc = rng.standard_normal((2, seq, kv_dim)).astype(np.float32)
+    vc = rng.standard_normal((2, seq, kv_dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    kc[1, 1500, :hs] = 3.0 * q[:hs]          # head 0 of group 0 sees one dominant key
+    kc[0, 700, hs:2 * hs] = -2.0 * q[dim - hs:]
+    ws = ops.mha_decode_workspace(heads, hs, seq, gpu)
+    assert ws is not None and ws.numel() > 0
+    kcd, vcd, qd = dev(kc, gpu), dev(vc, gpu), dev(q, gpu)
+    for layer in (0, 1):
+        for pos in (0, 100, 298, 299, 300, 511, 512, 767, 768, 1023, 1024, 1499, 1500, 2047,
+                    seq - 1):
+            out = torch.full((dim,), float("nan"), device=gpu)
+            ops.mha_decode(torch.tensor([pos], dtype=torch.int32, device=gpu), heads, layer,
+                           seq, kv_dim, kv_mul, hs, out, qd, kcd, vcd, ws)
+            oo, _ = oracle.mha(pos, heads, layer, seq, kv_dim, kv_mul, hs, q, kc, vc,
+                               acc=oracle.ACC_F64)
+            np.testing.assert_allclose(host(out), oo, rtol=0, atol=3e-5,
+                                       err_msg=f"heads {heads} layer {layer} pos {pos}")
+    assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
+
+
 # ---------------------------------------------------------------- CPU-only helpers of the reference
 def test_softmax_scale_scalesum(gpu, oracle):
     from kuiperllama_amd import ops
