@@ -22,7 +22,7 @@ EXPORTS = [
     "kh_model_create_from_file", "kh_model_create_from_host_image",
     "kh_model_create_from_device_weights", "kh_model_destroy", "kh_model_get_config",
     "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
-    "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
+    "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
 ]
 
 KH_EXEC_GRAPH, KH_EXEC_FUSED, KH_EXEC_UNFUSED = 0, 1, 2
@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
     L.kh_model_generate_until.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),
                                           _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32)]
     L.kh_model_time_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32)]
+    L.kh_model_prefill.argtypes = [_vp, C.POINTER(_i32), _i32, _i32]
     L.kh_model_profile_kernel.argtypes = [_vp, _i32, _i32, _i32, C.POINTER(_f32)]
     L.kh_model_profile_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32), C.POINTER(_i32)]
     L.kh_kclass_name.argtypes = [C.c_int]

@@ -617,6 +617,10 @@ struct KhAttnArgs {
   int ws_stride;           // split slots per head in the workspace (>= nsplit, >= nsplit_g)
   int nsplit_g;            // GQA long-context path: kv_heads * nsplit_g workgroups (0 = off)
   int t_long;              // the group path runs when pos + 1 >= t_long
+  // prefill (kh_prefill.h): gridDim.y tokens per launch, token t at position pos + t, its q /
+  // out rows tok_stride floats apart, its split workspace ws_tok_bytes apart (decode: y = 1)
+  int tok_stride;
+  size_t ws_tok_bytes;
 };
 
 // per-head path: block -> (kv group g, head-in-group j, split s).  Blocks are placed on XCD
@@ -641,9 +645,16 @@ __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem
 // only), so one captured launch serves every position; workgroups beyond the active path's
 // count leave immediately.
 template <int G, int KVM>
-__global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(const KhAttnArgs a, int host_pos) {
+__global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(KhAttnArgs a, int host_pos) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int pos = a.d_pos ? *a.d_pos : host_pos;
+  int pos = a.d_pos ? *a.d_pos : host_pos;
+  if (gridDim.y > 1) {  // uniform: one grid slice per prompt token
+    const int t = (int)blockIdx.y;
+    pos += t;
+    a.q += (size_t)t * a.tok_stride;
+    a.out += (size_t)t * a.tok_stride;
+    a.ws = (char*)a.ws + (size_t)t * a.ws_tok_bytes;
+  }
   const int b = (int)blockIdx.x;
   if (KVM == 0 || pos + 1 < a.t_long) {
     if (b < a.kv_heads * a.kv_mul * a.nsplit) attn_head_block<G>(a, (float*)smem_raw, b, pos);
@@ -677,7 +688,8 @@ static inline bool attn_group_supported(int head_size, int kv_mul, int wg) {
 }
 // Launch.  a.nsplit_g == 0 disables the group path; head_size > 32 required (callers route
 // smaller heads to the generic LDS-score kernel).
-static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStream_t s) {
+static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStream_t s,
+                                      int ntok = 1) {
   const int G = attn_lanes(a.head_size);
   const bool grp = a.nsplit_g > 0 && attn_group_supported(a.head_size, a.kv_mul, wg);
   if (!grp) a.nsplit_g = 0;
@@ -689,7 +701,7 @@ static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStr
     if (l2 > lds) lds = l2;
   }
 #define KH_ATTN_LAUNCH(GG, KK) \
-  hipLaunchKernelGGL((k_attn_decode<GG, KK>), dim3(grid), dim3(wg), lds, s, a, host_pos)
+  hipLaunchKernelGGL((k_attn_decode<GG, KK>), dim3(grid, ntok), dim3(wg), lds, s, a, host_pos)
   const int kvm = grp ? a.kv_mul : 0;
   if (G == 16) {
     switch (kvm) {

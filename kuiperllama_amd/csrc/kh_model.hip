@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "kh_merged.h"
+#include "kh_prefill.h"
 
 namespace {
 
@@ -65,6 +66,10 @@ struct kh_model {
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
+  // prefill (kh_prefill.h): residual / q / attention / hidden rows of KH_PF_B prompt tokens
+  float *pf_x = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
+  void* pf_ws = nullptr;        // KH_PF_B attention split workspaces
+  size_t pf_ws_tok_bytes = 0;
   int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check)
   int pin_cap = 0;
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
@@ -266,6 +271,8 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   a.ws_stride = m->attn_ws_stride;
   a.nsplit_g = m->attn_ns_g;
   a.t_long = m->attn_t_long;
+  a.tok_stride = 0;
+  a.ws_tok_bytes = 0;
   return a;
 }
 int attn_group_lanes(const kh_config& c) {
@@ -894,6 +901,8 @@ extern "C" void kh_model_destroy(kh_model* m) {
   if (m->graphN) (void)hipGraphDestroy(m->graphN);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
+  for (void* q : {(void*)m->pf_x, (void*)m->pf_q, (void*)m->pf_att, (void*)m->pf_h, m->pf_ws})
+    if (q) (void)hipFree(q);
   for (auto e : m->ev_chunk)
     if (e) (void)hipEventDestroy(e);
   if (m->h_words_pin) (void)hipHostFree(m->h_words_pin);
@@ -1059,6 +1068,191 @@ extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t
   return check_sync_err(m);
 }
 
+// ---- prompt prefill (kh_prefill.h) ---------------------------------------------------------------
+namespace {
+// The B-token kernels mirror the decode kernels' arithmetic only for the staging variant the
+// decode path uses at these sizes (in-register, MAXV = 4) and for the fast attention core.
+bool prefill_supported(const kh_model* m) {
+  const kh_config& c = m->cfg;
+  if (c.head_size <= 32 || m->merge_combo >= 0) return false;
+  if (kh_stage_maxv(c.dim, m->sh_qkv.wg) != 4 || kh_stage_maxv(c.dim, m->sh_ffn.wg) != 4) return false;
+  if (m->sh_qkv.split > 2 || m->sh_ffn.split != 1) return false;
+  if (pf_lds_bytes(c.is_quant, c.dim, KH_PF_B) > 160 * 1024) return false;
+  if (pf_lds_bytes(c.is_quant, c.hidden_dim, 2) > 160 * 1024) return false;
+  if (const char* e = getenv("KH_PREFILL"))
+    if (e[0] == '0') return false;
+  return true;
+}
+int ensure_prefill_buffers(kh_model* m) {
+  if (m->pf_x) return KH_OK;
+  const kh_config& c = m->cfg;
+  int rc;
+  if ((rc = dalloc(&m->pf_x, (size_t)KH_PF_B * c.dim)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->pf_q, (size_t)KH_PF_B * c.dim)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->pf_att, (size_t)KH_PF_B * c.dim)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->pf_h, (size_t)KH_PF_B * c.hidden_dim)) != KH_OK) return rc;
+  m->pf_ws_tok_bytes = (attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride) + 255) & ~(size_t)255;
+  if (m->pf_ws_tok_bytes) {
+    KH_CHECK_HIP(hipMalloc(&m->pf_ws, m->pf_ws_tok_bytes * KH_PF_B));
+    KH_CHECK_HIP(hipMemsetAsync(m->pf_ws, 0, m->pf_ws_tok_bytes * KH_PF_B, m->stream));
+  }
+  return KH_OK;
+}
+// The B-token kernels are register- and LDS-heavy: a grid larger than what is resident at once
+// runs in rounds and every round re-stages the B activation vectors, so the decode shape's grid
+// is clipped to one resident round (the result does not depend on the grid).
+template <class K, class A>
+void pf_launch(K kernel, int grid, int wg, size_t lds, hipStream_t s, const A& args) {
+  struct Cached {
+    const void* fn;
+    int wg;
+    size_t lds;
+    int resident;
+  };
+  static thread_local std::vector<Cached> cache;
+  int resident = 0;
+  for (const auto& c : cache)
+    if (c.fn == (const void*)kernel && c.wg == wg && c.lds == lds) resident = c.resident;
+  if (!resident) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, wg, lds) != hipSuccess ||
+        per_cu < 1)
+      per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        cus = v;
+    }
+    resident = per_cu * cus;
+    cache.push_back({(const void*)kernel, wg, lds, resident});
+  }
+  if (grid > resident) grid = resident;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(wg), lds, s, args);
+}
+template <int B>
+void pf_launch_gemv_res(kh_model* m, const kh_model::Shape& sh, const KhPfGemvResArgs& a) {
+  const bool q = m->cfg.is_quant;
+  const size_t lds = pf_lds_bytes(q, a.M, B);
+#define KH_PF_GR(QQ, SP) pf_launch(k_pf_gemv_res<QQ, SP, B>, sh.grid, sh.wg, lds, m->stream, a)
+  if (q) {
+    if (sh.split == 4) KH_PF_GR(true, 4); else if (sh.split == 2) KH_PF_GR(true, 2); else KH_PF_GR(true, 1);
+  } else {
+    if (sh.split == 4) KH_PF_GR(false, 4); else if (sh.split == 2) KH_PF_GR(false, 2); else KH_PF_GR(false, 1);
+  }
+#undef KH_PF_GR
+}
+// y = W.v ; X += y for the nvalid tokens of the chunk; halves when B vectors do not fit LDS
+void pf_gemv_res(kh_model* m, const kh_model::Shape& sh, const KhLin& w, const float* V, float* X,
+                 int M, int K, int nvalid) {
+  KhPfGemvResArgs a;
+  a.w = w;
+  a.M = M;
+  a.K = K;
+  a.gshift = m->gshift;
+  if (pf_lds_bytes(m->cfg.is_quant, M, KH_PF_B) <= 160 * 1024) {
+    a.V = V;
+    a.X = X;
+    a.nvalid = nvalid;
+    pf_launch_gemv_res<KH_PF_B>(m, sh, a);
+    return;
+  }
+  for (int t0 = 0; t0 < nvalid; t0 += 2) {
+    a.V = V + (size_t)t0 * M;
+    a.X = X + (size_t)t0 * K;
+    a.nvalid = nvalid - t0 < 2 ? nvalid - t0 : 2;
+    pf_launch_gemv_res<2>(m, sh, a);
+  }
+}
+// forward of nvalid (<= KH_PF_B) prompt tokens at positions pos0.. : fills their K/V cache rows
+void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0) {
+  const kh_config& c = m->cfg;
+  const bool q = c.is_quant;
+  KhPfTokens tk;
+  for (int b = 0; b < KH_PF_B; ++b) tk.t[b] = toks[b < nvalid ? b : nvalid - 1];
+  hipLaunchKernelGGL(k_pf_embed, dim3(KH_PF_B), dim3(KH_WG), 0, m->stream, tk, m->tok_emb, m->pf_x,
+                     c.dim);
+  for (int l = 0; l < c.layer_num; ++l) {
+    const LayerW& W = m->layers[l];
+    {
+      KhPfQkvArgs a;
+      a.X = m->pf_x;
+      a.att_norm = W.att_norm;
+      a.wq = W.wq;
+      a.wk = W.wk;
+      a.wv = W.wv;
+      a.Q = m->pf_q;
+      a.kcache_layer = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
+      a.vcache_layer = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
+      a.sin_cache = m->sin_cache;
+      a.cos_cache = m->cos_cache;
+      a.dim = c.dim;
+      a.kv_dim = c.kv_dim;
+      a.head_size = c.head_size;
+      a.rope_mode = c.rope_mode;
+      a.gshift = m->gshift;
+      a.pos0 = pos0;
+      a.nvalid = nvalid;
+      a.eps = c.rms_eps;
+      const size_t lds = pf_lds_bytes(q, c.dim, KH_PF_B);
+      const int grid = m->sh_qkv.grid, wg = m->sh_qkv.wg;
+      if (q) {
+        if (m->sh_qkv.split == 2) pf_launch(k_pf_qkv<true, 2>, grid, wg, lds, m->stream, a);
+        else pf_launch(k_pf_qkv<true, 1>, grid, wg, lds, m->stream, a);
+      } else {
+        if (m->sh_qkv.split == 2) pf_launch(k_pf_qkv<false, 2>, grid, wg, lds, m->stream, a);
+        else pf_launch(k_pf_qkv<false, 1>, grid, wg, lds, m->stream, a);
+      }
+    }
+    {
+      KhAttnArgs a = fill_attn(m, l);
+      a.q = m->pf_q;
+      a.out = m->pf_att;
+      a.d_pos = nullptr;
+      a.ws = m->pf_ws;
+      a.tok_stride = c.dim;
+      a.ws_tok_bytes = m->pf_ws_tok_bytes;
+      launch_attn_decode(a, pos0, m->attn_wg, m->stream, nvalid);
+    }
+    pf_gemv_res(m, m->sh_wo, W.wo, m->pf_att, m->pf_x, c.dim, c.dim, nvalid);
+    {
+      KhPfFfn13Args a;
+      a.X = m->pf_x;
+      a.ffn_norm = W.ffn_norm;
+      a.w1 = W.w1;
+      a.w3 = W.w3;
+      a.H = m->pf_h;
+      a.dim = c.dim;
+      a.hidden = c.hidden_dim;
+      a.gshift = m->gshift;
+      a.nvalid = nvalid;
+      a.eps = c.rms_eps;
+      const size_t lds = pf_lds_bytes(q, c.dim, KH_PF_B);
+      if (q) pf_launch(k_pf_ffn13<true>, m->sh_ffn.grid, m->sh_ffn.wg, lds, m->stream, a);
+      else pf_launch(k_pf_ffn13<false>, m->sh_ffn.grid, m->sh_ffn.wg, lds, m->stream, a);
+    }
+    pf_gemv_res(m, m->sh_w2, W.w2, m->pf_h, m->pf_x, c.hidden_dim, c.dim, nvalid);
+  }
+}
+}  // namespace
+
+extern "C" int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0) {
+  if (!m || !h_tokens || n <= 0 || pos0 < 0) return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if ((int64_t)pos0 + n > c.cache_len) return KH_ERR_RANGE;
+  for (int i = 0; i < n; ++i)
+    if (h_tokens[i] < 0 || h_tokens[i] >= c.vocab_size) return KH_ERR_RANGE;
+  if (!prefill_supported(m)) return KH_ERR_UNSUPPORTED;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  int rc;
+  if ((rc = ensure_prefill_buffers(m)) != KH_OK) return rc;
+  for (int t0 = 0; t0 < n; t0 += KH_PF_B)
+    launch_prefill_chunk(m, h_tokens + t0, n - t0 < KH_PF_B ? n - t0 : KH_PF_B, pos0 + t0);
+  return kh_launch_status();
+}
+
 extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
                                  int32_t total_steps, int32_t exec, int32_t* h_words,
                                  int32_t* n_words, float* h_elapsed_ms) {
@@ -1122,8 +1316,17 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   const int n_forced = m->seq_cap + 1;
   if (exec == KH_EXEC_GRAPH && (rc = ensure_graph(m, n_forced)) != KH_OK) return rc;
 
-  set_state(m, h_prompt[0], 0);
+  // prompt phase: the tokens that are only fed (positions 0 .. n_prompt-2) go through the
+  // B-tokens-per-weight-pass prefill when there are enough of them; it leaves exactly the K/V
+  // rows the token-by-token steps would (bit for bit), and the loop below starts at the last
+  // prompt token.  KH_PREFILL=0 keeps the reference's one-token-per-step prompt phase.
+  int start = 0;
   KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+  if (n_prompt - 1 >= 2 && n_prompt - 1 < total_steps && prefill_supported(m)) {
+    if ((rc = kh_model_prefill(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
+    start = n_prompt - 1;
+  }
+  set_state(m, h_prompt[start], start);
   auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps
     if (exec == KH_EXEC_GRAPH) {
       if (total_steps - s >= KH_GRAPH_STEPS) {
@@ -1138,7 +1341,7 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   };
   int n_out = total_steps;
   if (n_stop == 0) {
-    for (int s = 0; s < total_steps;) {
+    for (int s = start; s < total_steps;) {
       const int n = launch_chunk(s);
       if (n < 0) return (int)hipErrorUnknown;
       s += n;
@@ -1148,6 +1351,7 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     KH_CHECK_HIP(hipMemcpyAsync(h_words, m->d_words, sizeof(int32_t) * total_steps,
                                 hipMemcpyDeviceToHost, m->stream));
     KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < start; ++i) h_words[i] = h_prompt[i + 1];  // forced, main.cpp:36-38
   } else {
     // Stop-token check without a per-step host round trip: the words of every
     // chunk of steps are mirrored into pinned memory behind the chunk, and the host inspects
@@ -1156,7 +1360,8 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     if ((rc = ensure_pinned_words(m, total_steps)) != KH_OK) return rc;
     struct Chunk { int s0, n; };
     Chunk infl[2];
-    int n_infl = 0, head = 0, launched = 0, stop_at = -1;
+    int n_infl = 0, head = 0, launched = start, stop_at = -1;
+    for (int i = 0; i < start; ++i) m->h_words_pin[i] = h_prompt[i + 1];
     while (stop_at < 0 && (launched < total_steps || n_infl > 0)) {
       while (launched < total_steps && n_infl < 2) {
         const int n = launch_chunk(launched);

@@ -449,6 +449,8 @@ static int launch_mha_fast(const int32_t* d_pos, int32_t pos, int32_t head_num,
   a.ws_stride = ws_stride;
   a.nsplit_g = nsplit_g;
   a.t_long = t_long;
+  a.tok_stride = 0;
+  a.ws_tok_bytes = 0;
   launch_attn_decode(a, pos, KH_WG_MAX, s);
   return kh_launch_status();
 }

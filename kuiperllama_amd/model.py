@@ -136,6 +136,13 @@ class KuiperModel:
                    "kh_model_generate_until")
         return list(words[: n.value]), float(ms.value)
 
+    def prefill(self, tokens: Sequence[int], pos0: int = 0) -> None:
+        """Forward of `tokens` at positions pos0.. without logits, 4 tokens per weight pass; the
+        K/V rows are bit-identical to token-by-token predict(is_prompt=True)."""
+        t = (C.c_int32 * len(tokens))(*[int(x) for x in tokens])
+        _ffi.check(_ffi.lib().kh_model_prefill(self._h, t, len(tokens), pos0), "kh_model_prefill")
+        torch.cuda.synchronize()
+
     def time_step(self, pos: int, reps: int = 9) -> List[float]:
         """Microseconds of one graph-replayed decode step at `pos`, `reps` samples."""
         us = (C.c_float * reps)()

@@ -320,3 +320,96 @@ def test_full_size_baseline_shapes(gpu, oracle, preset, steps):
     want = om.generate(prompt, steps)
     assert g[:steps] == want
     m.close()
+
+
+# ---------------------------------------------------------------- prompt prefill (kh_prefill.h)
+_PF_SPECS = {
+    # mid-size stand-ins of the BASELINE geometries (head_size 64/128, GQA / MHA, bias, int8)
+    "gqa-half": binfmt.ModelSpec(512, 1536, 3, 8, 2, 640, 512, True, binfmt.FAMILY_LLAMA, False, 64,
+                                 binfmt.ROPE_HALF, 500000.0, 1e-5, "pf-gqa-half"),
+    "mha-interleaved": binfmt.ModelSpec(512, 1408, 2, 4, 4, 500, 512, False, binfmt.FAMILY_LLAMA,
+                                        False, 64, binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "pf-mha"),
+    "qwen-bias": binfmt.ModelSpec(448, 1216, 2, 7, 1, 700, 512, True, binfmt.FAMILY_QWEN2, False, 64,
+                                  binfmt.ROPE_HALF, 1000000.0, 1e-6, "pf-qwen"),
+    "int8": binfmt.ModelSpec(512, 1408, 2, 4, 4, 500, 512, False, binfmt.FAMILY_LLAMA, True, 64,
+                             binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "pf-int8"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_PF_SPECS))
+def test_prefill_is_bit_identical_to_token_by_token(gpu, name):
+    """kh_model_prefill (4 prompt tokens per weight pass) must leave exactly the K/V rows that
+    token-by-token forward passes leave, and the next step's logits must be identical too -
+    for chunk remainders 1..3, a non-zero start position and a position past the first attention
+    split (pos >= 256)."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = _PF_SPECS[name]
+    img_d, _ = _synth(spec, 77, gpu)
+    rng = np.random.default_rng(5)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, 320)]
+    a = KuiperModel.from_device_image(img_d, spec)
+    b = KuiperModel.from_device_image(img_d, spec)
+    pos = 0
+    for n in (1, 2, 3, 4, 5, 7, 8, 13, 230, 37):   # crosses pos 256 inside a chunk
+        seg = toks[pos:pos + n]
+        a.prefill(seg, pos)
+        for i, t in enumerate(seg):
+            b.predict(t, pos + i, is_prompt=True, exec="fused")
+        pos += n
+        for layer in range(spec.n_layers):
+            ka, va = a.read_kv(layer, 0, pos)
+            kb, vb = b.read_kv(layer, 0, pos)
+            assert np.array_equal(ka, kb), (name, n, layer, np.abs(ka - kb).max())
+            assert np.array_equal(va, vb), (name, n, layer, np.abs(va - vb).max())
+    na = a.predict(toks[pos], pos, exec="fused")
+    nb = b.predict(toks[pos], pos, exec="fused")
+    assert na == nb and np.array_equal(a.logits(), b.logits())
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("preset", ["llama3.2-1b", "llama2-7b-int8"])
+def test_prefill_full_size_bit_identical(gpu, preset):
+    """The same property at the full BASELINE shapes (incl. the w2 fallback to 2 tokens per pass
+    when 4 hidden-sized vectors exceed LDS: Llama-2-7B, hidden 11008)."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.PRESETS[preset]
+    img_d, _ = _synth(spec, 4321, gpu)
+    toks = [1, 263, 907, 11, 4012, 77, 1500, 29, 3000, 5, 17]
+    a = KuiperModel.from_device_image(img_d, spec, max_seq_len=256)
+    a.prefill(toks[:-1], 0)
+    ka = [a.read_kv(l, 0, len(toks) - 1) for l in (0, spec.n_layers - 1)]
+    na = a.predict(toks[-1], len(toks) - 1, exec="fused")
+    la = a.logits().copy()
+    a.close()
+    b = KuiperModel.from_device_image(img_d, spec, max_seq_len=256)
+    for i, t in enumerate(toks[:-1]):
+        b.predict(t, i, is_prompt=True, exec="fused")
+    kb = [b.read_kv(l, 0, len(toks) - 1) for l in (0, spec.n_layers - 1)]
+    nb = b.predict(toks[-1], len(toks) - 1, exec="fused")
+    for (k1, v1), (k2, v2) in zip(ka, kb):
+        assert np.array_equal(k1, k2) and np.array_equal(v1, v2)
+    assert na == nb and np.array_equal(la, b.logits())
+    b.close()
+
+
+def test_generate_with_long_prompt_uses_prefill_and_matches_oracle(gpu, oracle, monkeypatch):
+    """generate() sends the fed-only prompt tokens through the prefill; words, stop handling and
+    the token-by-token prompt phase (KH_PREFILL=0) agree with each other and with the oracle."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = _PF_SPECS["gqa-half"]
+    img_d, img_h = _synth(spec, 77, gpu)
+    prompt = [3, 17, 256, 9, 400, 31, 8, 630, 2, 99, 5]
+    steps = 96
+    om = oracle.OracleModel.from_spec(img_h, spec)
+    want = om.generate(prompt, steps)
+    m = KuiperModel.from_device_image(img_d, spec)
+    for mode in ("graph", "fused"):
+        got, _ = m.generate(prompt, steps, exec=mode)
+        assert got == want, (mode, next(i for i, (x, y) in enumerate(zip(got, want)) if x != y))
+    stop = [want[40]]
+    assert m.generate(prompt, steps, stop=stop)[0] == om.generate(prompt, steps, stop=stop)
+    monkeypatch.setenv("KH_PREFILL", "0")
+    got0, _ = m.generate(prompt, steps)
+    assert got0 == want
+    m.close()
