@@ -201,6 +201,22 @@ def measure(spec, args, rank, world, local_rank, primary):
             us = sorted(m.time_step(p, 9))
             lat[str(p)] = round(us[len(us) // 2], 2)
     out["latency_us_at_pos"] = lat
+    # prompt phase (extends the reference): 128 fed-only prompt tokens + 1 step, with
+    # the multi-token prefill and with the reference's one-token-per-step prompt phase
+    if args.steps >= 16:
+        rng = np.random.default_rng(0)
+        pp = [int(t) for t in rng.integers(0, spec.vocab_size, 129)]
+        pf = {}
+        for mode in ("1", "0"):
+            os.environ["KH_PREFILL"] = mode
+            m.generate(pp, len(pp), exec="graph")
+            pf[mode] = min(m.generate(pp, len(pp), exec="graph")[1] for _ in range(3))
+        os.environ.pop("KH_PREFILL", None)
+        out["prefill"] = {"prompt_tokens": len(pp) - 1,
+                          "prompt_tok_s": (len(pp) - 1) / (pf["1"] * 1e-3),
+                          "token_by_token_tok_s": (len(pp) - 1) / (pf["0"] * 1e-3),
+                          "speedup": pf["0"] / pf["1"],
+                          "note": "K/V rows bit-identical to the token-by-token prompt phase"}
     # per-kernel durations measured live with HIP events on the model's stream.  The roofline
     # figure uses back-to-back launches of the kernel over all layers between two events (no
     # event between launches); "kernels_avg_us_evented" is the whole step with an event after
@@ -270,7 +286,8 @@ def main():
                          "value": r2["value"], "unit": "tokens/s", "ms_per_step": r2["ms_per_step"],
                          "dtype": "int8 weights x f32 activations" if s2.quant else "f32",
                          "roofline": r2["roofline"], "runs": r2.get("runs"),
-                         "latency_us_at_pos": r2.get("latency_us_at_pos")}
+                         "latency_us_at_pos": r2.get("latency_us_at_pos"),
+                         "prefill": r2.get("prefill")}
         except Exception as e:  # the primary number must still be reported
             secondary = {"error": repr(e)}
 
@@ -289,6 +306,7 @@ def main():
                        "kv_cache_rows": spec.seq_len},
             "roofline": res["roofline"],
             "runs": res.get("runs"), "latency_us_at_pos": res.get("latency_us_at_pos"),
+            "prefill": res.get("prefill"),
         }
         if "cpu_baseline" in res:
             line["cpu_baseline"] = res["cpu_baseline"]

@@ -220,8 +220,8 @@ int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prom
                             float* h_elapsed_ms);
 
 /* Prompt prefill (extends the reference, which feeds prompt tokens one forward pass at a time,
- * demo/main.cpp:20-22): forward of tokens[0..n) at positions pos0.., 4 tokens per pass over the
- * weights, no logits.  Leaves the K/V cache rows pos0..pos0+n-1 BIT-IDENTICAL to n calls of
+ * demo/main.cpp:20-22): forward of tokens[0..n) at positions pos0.., 8 (fp32) or 4 (int8)
+ * tokens per pass over the weights, no logits.  Leaves the K/V cache rows pos0..pos0+n-1 BIT-IDENTICAL to n calls of
  * kh_model_predict(.., is_prompt = 1, KH_EXEC_FUSED).  kh_model_generate* use it for the
  * fed-only part of prompts of 3+ tokens (env KH_PREFILL=0 disables).  KH_ERR_UNSUPPORTED for
  * geometries outside the mirrored kernels (head_size <= 32, dim > 4096, merged launch). */

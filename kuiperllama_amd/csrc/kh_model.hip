@@ -66,9 +66,9 @@ struct kh_model {
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
-  // prefill (kh_prefill.h): residual / q / attention / hidden rows of KH_PF_B prompt tokens
+  // prefill (kh_prefill.h): residual / q / attention / hidden rows of up to KH_PF_BMAX prompt tokens
   float *pf_x = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
-  void* pf_ws = nullptr;        // KH_PF_B attention split workspaces
+  void* pf_ws = nullptr;        // KH_PF_BMAX attention split workspaces
   size_t pf_ws_tok_bytes = 0;
   int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check)
   int pin_cap = 0;
@@ -1070,6 +1070,12 @@ extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t
 
 // ---- prompt prefill (kh_prefill.h) ---------------------------------------------------------------
 namespace {
+// tokens per pass of the dim-input matrices (qkv, wo, ffn13)
+int prefill_batch(const kh_model* m) {
+  const kh_config& c = m->cfg;
+  if (!c.is_quant && pf_lds_bytes(false, c.dim, 8) <= 80 * 1024) return 8;
+  return 4;
+}
 // The B-token kernels mirror the decode kernels' arithmetic only for the staging variant the
 // decode path uses at these sizes (in-register, MAXV = 4) and for the fast attention core.
 bool prefill_supported(const kh_model* m) {
@@ -1077,7 +1083,7 @@ bool prefill_supported(const kh_model* m) {
   if (c.head_size <= 32 || m->merge_combo >= 0) return false;
   if (kh_stage_maxv(c.dim, m->sh_qkv.wg) != 4 || kh_stage_maxv(c.dim, m->sh_ffn.wg) != 4) return false;
   if (m->sh_qkv.split > 2 || m->sh_ffn.split != 1) return false;
-  if (pf_lds_bytes(c.is_quant, c.dim, KH_PF_B) > 160 * 1024) return false;
+  if (pf_lds_bytes(c.is_quant, c.dim, 4) > 160 * 1024) return false;
   if (pf_lds_bytes(c.is_quant, c.hidden_dim, 2) > 160 * 1024) return false;
   if (const char* e = getenv("KH_PREFILL"))
     if (e[0] == '0') return false;
@@ -1087,14 +1093,14 @@ int ensure_prefill_buffers(kh_model* m) {
   if (m->pf_x) return KH_OK;
   const kh_config& c = m->cfg;
   int rc;
-  if ((rc = dalloc(&m->pf_x, (size_t)KH_PF_B * c.dim)) != KH_OK) return rc;
-  if ((rc = dalloc(&m->pf_q, (size_t)KH_PF_B * c.dim)) != KH_OK) return rc;
-  if ((rc = dalloc(&m->pf_att, (size_t)KH_PF_B * c.dim)) != KH_OK) return rc;
-  if ((rc = dalloc(&m->pf_h, (size_t)KH_PF_B * c.hidden_dim)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->pf_x, (size_t)KH_PF_BMAX * c.dim)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->pf_q, (size_t)KH_PF_BMAX * c.dim)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->pf_att, (size_t)KH_PF_BMAX * c.dim)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->pf_h, (size_t)KH_PF_BMAX * c.hidden_dim)) != KH_OK) return rc;
   m->pf_ws_tok_bytes = (attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride) + 255) & ~(size_t)255;
   if (m->pf_ws_tok_bytes) {
-    KH_CHECK_HIP(hipMalloc(&m->pf_ws, m->pf_ws_tok_bytes * KH_PF_B));
-    KH_CHECK_HIP(hipMemsetAsync(m->pf_ws, 0, m->pf_ws_tok_bytes * KH_PF_B, m->stream));
+    KH_CHECK_HIP(hipMalloc(&m->pf_ws, m->pf_ws_tok_bytes * KH_PF_BMAX));
+    KH_CHECK_HIP(hipMemsetAsync(m->pf_ws, 0, m->pf_ws_tok_bytes * KH_PF_BMAX, m->stream));
   }
   return KH_OK;
 }
@@ -1132,48 +1138,60 @@ void pf_launch(K kernel, int grid, int wg, size_t lds, hipStream_t s, const A& a
   if (grid > resident) grid = resident;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(wg), lds, s, args);
 }
-template <int B>
+template <bool Q, int B>
 void pf_launch_gemv_res(kh_model* m, const kh_model::Shape& sh, const KhPfGemvResArgs& a) {
-  const bool q = m->cfg.is_quant;
-  const size_t lds = pf_lds_bytes(q, a.M, B);
-#define KH_PF_GR(QQ, SP) pf_launch(k_pf_gemv_res<QQ, SP, B>, sh.grid, sh.wg, lds, m->stream, a)
-  if (q) {
-    if (sh.split == 4) KH_PF_GR(true, 4); else if (sh.split == 2) KH_PF_GR(true, 2); else KH_PF_GR(true, 1);
-  } else {
-    if (sh.split == 4) KH_PF_GR(false, 4); else if (sh.split == 2) KH_PF_GR(false, 2); else KH_PF_GR(false, 1);
-  }
-#undef KH_PF_GR
+  const size_t lds = pf_lds_bytes(Q, a.M, B);
+  if (sh.split == 4)
+    pf_launch(k_pf_gemv_res<Q, 4, B>, sh.grid, sh.wg, lds, m->stream, a);
+  else if (sh.split == 2)
+    pf_launch(k_pf_gemv_res<Q, 2, B>, sh.grid, sh.wg, lds, m->stream, a);
+  else
+    pf_launch(k_pf_gemv_res<Q, 1, B>, sh.grid, sh.wg, lds, m->stream, a);
 }
-// y = W.v ; X += y for the nvalid tokens of the chunk; halves when B vectors do not fit LDS
+// y = W.v ; X += y for the nvalid tokens of the chunk, in sub-batches of the largest of 8/4/2
+// tokens (<= bmax) whose input vectors fit LDS
 void pf_gemv_res(kh_model* m, const kh_model::Shape& sh, const KhLin& w, const float* V, float* X,
-                 int M, int K, int nvalid) {
+                 int M, int K, int nvalid, int bmax) {
+  const bool q = m->cfg.is_quant;
+  int bs = bmax;
+  while (bs > 2 && pf_lds_bytes(q, M, bs) > 160 * 1024) bs >>= 1;
   KhPfGemvResArgs a;
   a.w = w;
   a.M = M;
   a.K = K;
   a.gshift = m->gshift;
-  if (pf_lds_bytes(m->cfg.is_quant, M, KH_PF_B) <= 160 * 1024) {
-    a.V = V;
-    a.X = X;
-    a.nvalid = nvalid;
-    pf_launch_gemv_res<KH_PF_B>(m, sh, a);
-    return;
-  }
-  for (int t0 = 0; t0 < nvalid; t0 += 2) {
+  for (int t0 = 0; t0 < nvalid; t0 += bs) {
     a.V = V + (size_t)t0 * M;
     a.X = X + (size_t)t0 * K;
-    a.nvalid = nvalid - t0 < 2 ? nvalid - t0 : 2;
-    pf_launch_gemv_res<2>(m, sh, a);
+    a.nvalid = nvalid - t0 < bs ? nvalid - t0 : bs;
+    if (q) {
+      if (bs >= 4) pf_launch_gemv_res<true, 4>(m, sh, a); else pf_launch_gemv_res<true, 2>(m, sh, a);
+    } else {
+      if (bs == 8) pf_launch_gemv_res<false, 8>(m, sh, a);
+      else if (bs == 4) pf_launch_gemv_res<false, 4>(m, sh, a);
+      else pf_launch_gemv_res<false, 2>(m, sh, a);
+    }
   }
 }
-// forward of nvalid (<= KH_PF_B) prompt tokens at positions pos0.. : fills their K/V cache rows
-void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0) {
+template <bool Q, int B>
+void pf_launch_qkv(kh_model* m, const KhPfQkvArgs& a) {
+  const size_t lds = pf_lds_bytes(Q, a.dim, B);
+  if (m->sh_qkv.split == 2)
+    pf_launch(k_pf_qkv<Q, 2, B>, m->sh_qkv.grid, m->sh_qkv.wg, lds, m->stream, a);
+  else
+    pf_launch(k_pf_qkv<Q, 1, B>, m->sh_qkv.grid, m->sh_qkv.wg, lds, m->stream, a);
+}
+template <bool Q, int B>
+void pf_launch_ffn13(kh_model* m, const KhPfFfn13Args& a) {
+  pf_launch(k_pf_ffn13<Q, B>, m->sh_ffn.grid, m->sh_ffn.wg, pf_lds_bytes(Q, a.dim, B), m->stream, a);
+}
+// forward of nvalid (<= B) prompt tokens at positions pos0.. : fills their K/V cache rows
+void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0, int B) {
   const kh_config& c = m->cfg;
   const bool q = c.is_quant;
   KhPfTokens tk;
-  for (int b = 0; b < KH_PF_B; ++b) tk.t[b] = toks[b < nvalid ? b : nvalid - 1];
-  hipLaunchKernelGGL(k_pf_embed, dim3(KH_PF_B), dim3(KH_WG), 0, m->stream, tk, m->tok_emb, m->pf_x,
-                     c.dim);
+  for (int b = 0; b < KH_PF_BMAX; ++b) tk.t[b] = toks[b < nvalid ? b : nvalid - 1];
+  hipLaunchKernelGGL(k_pf_embed, dim3(B), dim3(KH_WG), 0, m->stream, tk, m->tok_emb, m->pf_x, c.dim);
   for (int l = 0; l < c.layer_num; ++l) {
     const LayerW& W = m->layers[l];
     {
@@ -1196,15 +1214,9 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
       a.pos0 = pos0;
       a.nvalid = nvalid;
       a.eps = c.rms_eps;
-      const size_t lds = pf_lds_bytes(q, c.dim, KH_PF_B);
-      const int grid = m->sh_qkv.grid, wg = m->sh_qkv.wg;
-      if (q) {
-        if (m->sh_qkv.split == 2) pf_launch(k_pf_qkv<true, 2>, grid, wg, lds, m->stream, a);
-        else pf_launch(k_pf_qkv<true, 1>, grid, wg, lds, m->stream, a);
-      } else {
-        if (m->sh_qkv.split == 2) pf_launch(k_pf_qkv<false, 2>, grid, wg, lds, m->stream, a);
-        else pf_launch(k_pf_qkv<false, 1>, grid, wg, lds, m->stream, a);
-      }
+      if (q) pf_launch_qkv<true, 4>(m, a);
+      else if (B == 8) pf_launch_qkv<false, 8>(m, a);
+      else pf_launch_qkv<false, 4>(m, a);
     }
     {
       KhAttnArgs a = fill_attn(m, l);
@@ -1216,7 +1228,7 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
       a.ws_tok_bytes = m->pf_ws_tok_bytes;
       launch_attn_decode(a, pos0, m->attn_wg, m->stream, nvalid);
     }
-    pf_gemv_res(m, m->sh_wo, W.wo, m->pf_att, m->pf_x, c.dim, c.dim, nvalid);
+    pf_gemv_res(m, m->sh_wo, W.wo, m->pf_att, m->pf_x, c.dim, c.dim, nvalid, B);
     {
       KhPfFfn13Args a;
       a.X = m->pf_x;
@@ -1229,11 +1241,11 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
       a.gshift = m->gshift;
       a.nvalid = nvalid;
       a.eps = c.rms_eps;
-      const size_t lds = pf_lds_bytes(q, c.dim, KH_PF_B);
-      if (q) pf_launch(k_pf_ffn13<true>, m->sh_ffn.grid, m->sh_ffn.wg, lds, m->stream, a);
-      else pf_launch(k_pf_ffn13<false>, m->sh_ffn.grid, m->sh_ffn.wg, lds, m->stream, a);
+      if (q) pf_launch_ffn13<true, 4>(m, a);
+      else if (B == 8) pf_launch_ffn13<false, 8>(m, a);
+      else pf_launch_ffn13<false, 4>(m, a);
     }
-    pf_gemv_res(m, m->sh_w2, W.w2, m->pf_h, m->pf_x, c.hidden_dim, c.dim, nvalid);
+    pf_gemv_res(m, m->sh_w2, W.w2, m->pf_h, m->pf_x, c.hidden_dim, c.dim, nvalid, B);
   }
 }
 }  // namespace
@@ -1248,8 +1260,9 @@ extern "C" int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n,
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
   int rc;
   if ((rc = ensure_prefill_buffers(m)) != KH_OK) return rc;
-  for (int t0 = 0; t0 < n; t0 += KH_PF_B)
-    launch_prefill_chunk(m, h_tokens + t0, n - t0 < KH_PF_B ? n - t0 : KH_PF_B, pos0 + t0);
+  const int B = prefill_batch(m);
+  for (int t0 = 0; t0 < n; t0 += B)
+    launch_prefill_chunk(m, h_tokens + t0, n - t0 < B ? n - t0 : B, pos0 + t0, B);
   return kh_launch_status();
 }
 

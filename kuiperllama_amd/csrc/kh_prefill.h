@@ -1,8 +1,8 @@
-// kh_prefill.h — prompt prefill: KH_PF_B prompt tokens per pass over the weights.
+// kh_prefill.h — prompt prefill: several prompt tokens per pass over the weights.
 //
 // The reference feeds the prompt one token per forward pass (demo/main.cpp:20-22), so every
 // prompt token streams all weights once.  Here B consecutive prompt tokens share ONE pass: the
-// row-pair GEMV core keeps B activation vectors in LDS and B accumulator pairs per wave, so the
+// row-pair GEMV core keeps B (4 or 8) activation vectors in LDS and B accumulator pairs per wave, so the
 // weight bytes per prompt token drop by B while the kernels stay HBM-bound (B = 4: 4 FMA per
 // weight byte-quad, ~10 % of the VALU rate at the HBM rate).  No logits are produced for prompt
 // tokens (the reference computes and discards them); what the prompt phase leaves behind — the
@@ -18,7 +18,10 @@
 #pragma once
 #include "kh_fused.h"
 
-#define KH_PF_B 4   // tokens per weight pass (w2 falls back to 2 when B hidden vectors exceed LDS)
+// Tokens per weight pass: up to 8 for the dim-input matrices of fp32 models when 8 vectors leave
+// room for two workgroups per CU, else 4; w2 (hidden-sized input) takes the largest of 8/4/2 whose
+// vectors fit LDS; int8 stays at 4 (its converted-weight tile already fills the register file).
+#define KH_PF_BMAX 8
 // 16-byte loads per row in flight per lane: int8 converts the whole tile to floats once per
 // chunk (16 floats per load), so its tile is kept to 2 loads per row
 #define KH_PF_U(QUANT) ((QUANT) ? 2 : 4)
@@ -271,7 +274,7 @@ __device__ __forceinline__ int pf_xstride(int M) {  // f32x4 slots per staged to
 
 // ---- kernels ------------------------------------------------------------------------------------
 struct KhPfTokens {
-  int32_t t[KH_PF_B];
+  int32_t t[KH_PF_BMAX];
 };
 // embedding rows of the B tokens -> X[B][dim]   (emb_kernel.cu / model.cpp:245-263 fill_input)
 __global__ __launch_bounds__(KH_WG) void k_pf_embed(KhPfTokens tok, const float* __restrict__ emb,
@@ -295,9 +298,9 @@ struct KhPfQkvArgs {
   int pos0, nvalid;       // token b sits at position pos0 + b; tokens >= nvalid are padding
   float eps;
 };
-template <bool QUANT, int SPLIT>
+template <bool QUANT, int SPLIT, int B>
 __global__ __launch_bounds__(KH_WG_MAX) void k_pf_qkv(const KhPfQkvArgs a) {
-  constexpr int B = KH_PF_B, U = KH_PF_U(QUANT);
+  constexpr int U = KH_PF_U(QUANT);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const void *wq_w = a.wq.w, *wk_w = a.wk.w, *wv_w = a.wv.w;
   const float *wq_s = a.wq.scales, *wk_s = a.wk.scales, *wv_s = a.wv.scales;
@@ -405,9 +408,9 @@ struct KhPfFfn13Args {
   int dim, hidden, gshift, nvalid;
   float eps;
 };
-template <bool QUANT>
+template <bool QUANT, int B>
 __global__ __launch_bounds__(KH_WG_MAX) void k_pf_ffn13(const KhPfFfn13Args a) {
-  constexpr int B = KH_PF_B, U = KH_PF_U(QUANT);
+  constexpr int U = KH_PF_U(QUANT);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const void *w1 = a.w1.w, *w3 = a.w3.w;
   const float *s1p = a.w1.scales, *s3p = a.w3.scales;

@@ -338,7 +338,7 @@ _PF_SPECS = {
 
 @pytest.mark.parametrize("name", sorted(_PF_SPECS))
 def test_prefill_is_bit_identical_to_token_by_token(gpu, name):
-    """kh_model_prefill (4 prompt tokens per weight pass) must leave exactly the K/V rows that
+    """kh_model_prefill (4 or 8 prompt tokens per weight pass) must leave exactly the K/V rows that
     token-by-token forward passes leave, and the next step's logits must be identical too -
     for chunk remainders 1..3, a non-zero start position and a position past the first attention
     split (pos >= 256)."""

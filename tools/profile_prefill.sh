@@ -1,5 +1,5 @@
 R=$PWD; export TMPDIR=/tmp; cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pf_prof -o pf -- python $R/tools/bench_prefill.py llama3.2-1b > $R/gpurun_out/pf_prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pf_prof -o pf -- python $R/tools/bench_prefill.py ${1:-llama3.2-1b} > $R/gpurun_out/pf_prof.log 2>&1
 cd $R
 python - <<'PY'
 import sqlite3,glob,re
