@@ -24,7 +24,17 @@ def init_from_env(backend: str, device: torch.device | None = None) -> Tuple[int
         os.environ.setdefault("MASTER_PORT", "29511")
         if not dist.is_initialized():
             kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            try:
+                dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            except Exception as e:  # noqa: BLE001
+                # The replicas exchange nothing but the timing protocol (a barrier and one
+                # 8-byte max-reduce): if RCCL cannot come up on this node, gloo over the host
+                # carries it just as well and the measurement is unaffected.
+                if backend != "nccl":
+                    raise
+                print(f"[replicas] RCCL init failed ({e!r}); timing protocol falls back to gloo",
+                      flush=True)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
     return rank, world, local_rank
 
 
@@ -48,7 +58,8 @@ def timed_replica_run(run: Callable[[], float | None], steps: int, world: int,
         dist.barrier()
     wall = t1 - t0
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        red_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([wall], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, world * steps / wall

@@ -336,13 +336,16 @@ _PF_SPECS = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(_PF_SPECS))
-def test_prefill_is_bit_identical_to_token_by_token(gpu, name):
+@pytest.mark.parametrize("name", sorted(_PF_SPECS) + ["gqa-half+group-path", "qwen-bias+group-path"])
+def test_prefill_is_bit_identical_to_token_by_token(gpu, name, monkeypatch):
     """kh_model_prefill (4 or 8 prompt tokens per weight pass) must leave exactly the K/V rows that
     token-by-token forward passes leave, and the next step's logits must be identical too -
     for chunk remainders 1..3, a non-zero start position and a position past the first attention
     split (pos >= 256)."""
     from kuiperllama_amd.model import KuiperModel
+    if name.endswith("+group-path"):  # GQA group attention (kh_attn.h) from position 64 on
+        monkeypatch.setenv("KH_ATTN_TLONG", "64")
+        name = name.split("+")[0]
     spec = _PF_SPECS[name]
     img_d, _ = _synth(spec, 77, gpu)
     rng = np.random.default_rng(5)
