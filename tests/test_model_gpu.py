@@ -301,7 +301,8 @@ def test_profile_step_reports_all_kernel_classes(gpu):
     m.close()
 
 
-@pytest.mark.parametrize("preset,steps", [("llama3.2-1b", 24), ("qwen2.5-0.5b", 24)])
+@pytest.mark.parametrize("preset,steps", [("llama3.2-1b", 24), ("qwen2.5-0.5b", 24),
+                                          ("llama2-7b-int8", 8)])
 def test_full_size_baseline_shapes(gpu, oracle, preset, steps):
     """BASELINE.json configs at full size: token parity with the CPU oracle on a bounded number
     of steps, plus a size-independent property — graph replay == eager fused == unfused
