@@ -44,6 +44,40 @@ __device__ __forceinline__ void fma_chunk_b(const RegsF32<U>& r, const f32x4* xs
     }
   }
 }
+// int8: the 16 weights of a load are converted to float ONCE per row and reused by all B tokens
+// (the decode kernels convert inside dot4_i8; the value sequence fed to the FMA chain is the same:
+// t = fma(w_0, x_0, 0), fma(w_1, x_1, t), ... over the 16 weights, then a = fma(scale, t, a)).
+__device__ __forceinline__ void cvt16_i8(const i32x4& q, float (&w)[16]) {
+  const int d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w[4 * k + 0] = (float)(int8_t)(d[k] & 0xff);
+    w[4 * k + 1] = (float)(int8_t)((d[k] >> 8) & 0xff);
+    w[4 * k + 2] = (float)(int8_t)((d[k] >> 16) & 0xff);
+    w[4 * k + 3] = (float)(d[k] >> 24);
+  }
+}
+__device__ __forceinline__ float dot16(const float (&w)[16], const f32x4& x0, const f32x4& x1,
+                                       const f32x4& x2, const f32x4& x3) {
+  float t = 0.f;
+  t = __builtin_fmaf(w[0], x0.x, t);
+  t = __builtin_fmaf(w[1], x0.y, t);
+  t = __builtin_fmaf(w[2], x0.z, t);
+  t = __builtin_fmaf(w[3], x0.w, t);
+  t = __builtin_fmaf(w[4], x1.x, t);
+  t = __builtin_fmaf(w[5], x1.y, t);
+  t = __builtin_fmaf(w[6], x1.z, t);
+  t = __builtin_fmaf(w[7], x1.w, t);
+  t = __builtin_fmaf(w[8], x2.x, t);
+  t = __builtin_fmaf(w[9], x2.y, t);
+  t = __builtin_fmaf(w[10], x2.z, t);
+  t = __builtin_fmaf(w[11], x2.w, t);
+  t = __builtin_fmaf(w[12], x3.x, t);
+  t = __builtin_fmaf(w[13], x3.y, t);
+  t = __builtin_fmaf(w[14], x3.z, t);
+  t = __builtin_fmaf(w[15], x3.w, t);
+  return t;
+}
 template <int U, int B>
 __device__ __forceinline__ void fma_chunk_b(const RegsQ8<U>& r, const f32x4* xs, int xstride,
                                             int c0, int M16, int plane, int lane, float (&a0)[B],
@@ -53,27 +87,21 @@ __device__ __forceinline__ void fma_chunk_b(const RegsQ8<U>& r, const f32x4* xs,
   for (int u = 0; u < U; ++u) {
     const int idx = c0 + u * KH_WAVE + lane;
     if (idx < M16) {
+      float w0[16], w1[16];
+      cvt16_i8(r.q0[u], w0);
+      cvt16_i8(r.q1[u], w1);
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         const f32x4* xb = xs + (size_t)b * xstride;
         const f32x4 x0 = xb[idx], x1 = xb[plane + idx], x2 = xb[2 * plane + idx],
                     x3 = xb[3 * plane + idx];
-        float t0 = 0.f, t1 = 0.f;
-        t0 = dot4_i8(r.q0[u].x, x0, t0);
-        t0 = dot4_i8(r.q0[u].y, x1, t0);
-        t0 = dot4_i8(r.q0[u].z, x2, t0);
-        t0 = dot4_i8(r.q0[u].w, x3, t0);
-        t1 = dot4_i8(r.q1[u].x, x0, t1);
-        t1 = dot4_i8(r.q1[u].y, x1, t1);
-        t1 = dot4_i8(r.q1[u].z, x2, t1);
-        t1 = dot4_i8(r.q1[u].w, x3, t1);
-        a0[b] = __builtin_fmaf(r.g0[u], t0, a0[b]);
-        a1[b] = __builtin_fmaf(r.g1[u], t1, a1[b]);
-        // keep the next token's 4 LDS reads from being hoisted above this token's FMAs: with
-        // all B tokens' operands live at once the kernel needs > 230 VGPRs
+        a0[b] = __builtin_fmaf(r.g0[u], dot16(w0, x0, x1, x2, x3), a0[b]);
+        a1[b] = __builtin_fmaf(r.g1[u], dot16(w1, x0, x1, x2, x3), a1[b]);
+        // keep the next token's LDS reads below this token's FMAs (bounds the live operands)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 template <bool QUANT, int U, int B>
