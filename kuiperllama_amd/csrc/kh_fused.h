@@ -251,6 +251,9 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_attn_generic(const KhAttnArgs a) 
                    a.out + (size_t)h * a.head_size, nullptr, (float*)smem_raw);
 }
 
+#ifndef KH_EXP_NOSTAGE
+#define KH_EXP_NOSTAGE 0  // ablation switch (tools/exp_int8.sh): skip the input staging of wo / w2
+#endif
 // ---------------------------------------------------------------------------------------------
 // y = W . v ; x += y      (wo and w2 with their residual adds, llama3.cpp:670-686, 710-719)
 struct KhGemvResArgs {
@@ -291,14 +294,20 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem
   gemv_pairs<QUANT, U, SPLIT>(
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) {
+#if !KH_EXP_NOSTAGE
         if (!MERGED) st.issue();
+#endif
       },
       [&]() __attribute__((always_inline)) {
+#if KH_EXP_NOSTAGE
+        __syncthreads();  // ablation: x is never staged (wrong results; staging cost upper bound)
+#else
         if (MERGED) {
           wait_counter<32>(cnt_attn + (vb & (KH_SYNC_REPL - 1)) * KH_SYNC_STRIDE, expect_attn, err);
           st.issue();
         }
         st.finish(xs, 0.f, red);
+#endif
       },
       epi, vb, vgrid);
 }

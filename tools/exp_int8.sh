@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 L=kuiperllama_amd/lib; C=kuiperllama_amd/csrc
-for v in BPERM:KH_SCALE_BPERM NOSCALE:KH_EXP_NOSCALE NOLDS:KH_EXP_NOLDS NOCVT:KH_EXP_NOCVT; do
+for v in NOSTAGE:KH_EXP_NOSTAGE NOSCALE:KH_EXP_NOSCALE NOLDS:KH_EXP_NOLDS NOCVT:KH_EXP_NOCVT; do
   name=${v%%:*}; mac=${v##*:}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -shared -D${mac}=1 $C/kh_ops.hip $C/kh_model.hip -o $L/exp_${name}.so &
 done
