@@ -255,6 +255,25 @@ int kh_model_profile_step(kh_model* m, int32_t start_pos, int32_t n_steps, float
                           int32_t* h_count);
 const char* kh_kclass_name(int kclass);
 
+/* ---- Tokenizer: SentencePiece BPE (host only) -------------------------------------------------
+ * Replaces op::SpeEncodeLayer (kuiper/source/op/encode.cpp:10-57), the reference's wrapper over
+ * the external sentencepiece library: Load -> create, Encode (+bos/eos like encode.cpp:37-44),
+ * Decode, eos_id (is_sentence_ending, encode.cpp:48-51), GetPieceSize.  BPE model files with the
+ * identity character map (Llama-2's tokenizer.model); anything else -> KH_ERR_UNSUPPORTED.
+ * encode/decode return KH_ERR_RANGE when the output does not fit and store the needed size. */
+typedef struct kh_spm kh_spm;
+int kh_spm_create_from_file(const char* tokenizer_model_path, kh_spm** out);
+int kh_spm_create_from_memory(const void* model_proto, int64_t nbytes, kh_spm** out);
+void kh_spm_destroy(kh_spm* t);
+int32_t kh_spm_vocab_size(const kh_spm* t);
+int32_t kh_spm_bos_id(const kh_spm* t);
+int32_t kh_spm_eos_id(const kh_spm* t);
+int32_t kh_spm_unk_id(const kh_spm* t);
+int kh_spm_encode(const kh_spm* t, const char* utf8, int64_t len, int32_t add_bos, int32_t add_eos,
+                  int32_t* out_ids, int32_t cap, int32_t* n_ids);
+int kh_spm_decode(const kh_spm* t, const int32_t* ids, int32_t n, char* out_utf8, int64_t cap,
+                  int64_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

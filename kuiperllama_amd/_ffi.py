@@ -22,11 +22,14 @@ EXPORTS = [
     "kh_model_create_from_file", "kh_model_create_from_host_image",
     "kh_model_create_from_device_weights", "kh_model_destroy", "kh_model_get_config",
     "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
+    "kh_spm_create_from_file", "kh_spm_create_from_memory", "kh_spm_destroy", "kh_spm_vocab_size",
+    "kh_spm_bos_id", "kh_spm_eos_id", "kh_spm_unk_id", "kh_spm_encode", "kh_spm_decode",
     "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
 ]
 
 KH_EXEC_GRAPH, KH_EXEC_FUSED, KH_EXEC_UNFUSED = 0, 1, 2
 KH_NUM_KCLASS = 7
+KH_ERR_RANGE = -6
 
 
 class KhError(RuntimeError):
@@ -112,6 +115,17 @@ def lib() -> C.CDLL:
     L.kh_model_generate_until.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),
                                           _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32)]
     L.kh_model_time_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32)]
+    L.kh_spm_create_from_file.argtypes = [C.c_char_p, C.POINTER(_vp)]
+    L.kh_spm_create_from_memory.argtypes = [_vp, C.c_int64, C.POINTER(_vp)]
+    L.kh_spm_destroy.argtypes = [_vp]
+    L.kh_spm_destroy.restype = None
+    for fn in (L.kh_spm_vocab_size, L.kh_spm_bos_id, L.kh_spm_eos_id, L.kh_spm_unk_id):
+        fn.argtypes = [_vp]
+        fn.restype = _i32
+    L.kh_spm_encode.argtypes = [_vp, C.c_char_p, C.c_int64, _i32, _i32, C.POINTER(_i32), _i32,
+                                C.POINTER(_i32)]
+    L.kh_spm_decode.argtypes = [_vp, C.POINTER(_i32), _i32, C.c_char_p, C.c_int64,
+                                C.POINTER(C.c_int64)]
     L.kh_model_prefill.argtypes = [_vp, C.POINTER(_i32), _i32, _i32]
     L.kh_model_profile_kernel.argtypes = [_vp, _i32, _i32, _i32, C.POINTER(_f32)]
     L.kh_model_profile_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32), C.POINTER(_i32)]

@@ -15,8 +15,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkuiper_hip.so")
-SOURCES = ["kh_ops.hip", "kh_model.hip"]
-HEADERS = ["kh_common.h", "kh_gemv.h", "kh_attn.h", "kh_fused.h", "../../include/kuiper_hip.h"]
+SOURCES = ["kh_ops.hip", "kh_model.hip", "kh_tokenizer.cpp"]
+HEADERS = ["kh_common.h", "kh_gemv.h", "kh_attn.h", "kh_fused.h", "kh_merged.h", "kh_prefill.h",
+           "../../include/kuiper_hip.h"]
 ARCH = "gfx950"
 
 
@@ -44,7 +45,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
                # no implicit FMA contraction: results must not depend on which kernel a stage is
                # inlined into (merged vs stand-alone launches are compared bit for bit) and the

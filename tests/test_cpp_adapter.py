@@ -1,5 +1,6 @@
 """C++ host adapter (include/kuiper_hip_adapter.hpp): kernels_interface.h-shaped functions over
 the C-ABI, exercised by a C++ program that restates the reference's own op tests."""
+import os
 import subprocess
 
 import pytest
@@ -48,6 +49,37 @@ def test_demo_cli_matches_oracle(gpu, oracle, tmp_path, mode):
     ids = [int(t) for t in lines[1].split()]
     assert ids == want
     assert lines[2].startswith("steps/s:")
+
+
+@pytest.mark.gpu
+def test_demo_cli_text_prompt_with_sentencepiece_tokenizer(gpu, oracle, tmp_path):
+    """--tokenizer/--text: BOS + SentencePiece-BPE encode (SpeEncodeLayer), stop at eos, decoded text
+    printed like demo/main.cpp:43-45; ids equal the oracle's run on the same prompt ids and the
+    printed text equals the sentencepiece library's decode of them."""
+    import torch
+    from conftest import GOLDEN
+    from kuiperllama_amd import binfmt
+    from kuiperllama_amd.tokenizer import SpmTokenizer
+    spec = binfmt.ModelSpec(256, 512, 2, 4, 2, 448, 128, True, binfmt.FAMILY_LLAMA, False, 64,
+                            binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "demo-tok")
+    img = binfmt.synth_image(spec, seed=11, device=torch.device("cpu")).numpy()
+    path = tmp_path / "m.bin"
+    img.tofile(path)
+    tok_path = os.path.join(GOLDEN, "spm_llama_like.model")
+    tok = SpmTokenizer.from_file(tok_path)
+    text = "Once upon a time there was a little dragon"
+    prompt = tok.encode(text)
+    assert prompt[0] == tok.bos_id and len(prompt) > 3
+    want = oracle.OracleModel.from_spec(img, spec).generate(prompt, 40, stop=[tok.eos_id])
+    exe = build.build_demo()
+    r = subprocess.run([exe, str(path), "--steps", "40", "--tokenizer", tok_path, "--text", text],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.split("\n")
+    assert [int(t) for t in lines[2].split()] == want
+    assert lines[1].rstrip(" ") == tok.decode(want).rstrip(" ")
+    spm = pytest.importorskip("sentencepiece")
+    assert tok.decode(want) == spm.SentencePieceProcessor(model_file=tok_path).decode(want)
 
 
 def test_demo_cli_builds_and_fails_loudly_without_gpu(tmp_path):

@@ -1,11 +1,14 @@
 // kuiper_demo — command-line twin of the reference's demo/main.cpp / demo/main_qwen.cpp on top of
 // the C-ABI (include/kuiper_hip.h).  The reference hard-codes tokenizer type, quantisation,
-// device and prompt in the source; here they are flags.  Tokenisation is out of
-// scope, so the prompt is given as token ids and ids are printed.
+// device and prompt in the source; here they are flags.  The prompt is given as
+// token ids (--prompt) or, with a SentencePiece-BPE tokenizer.model (--tokenizer, the reference's
+// second argument, main.cpp:56), as text (--text): BOS + encode like SpeEncodeLayer, stop at
+// eos_id, decoded text printed like main.cpp:43-45.
 //
 //   kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]
 //               [--theta 10000] [--eps 1e-5] [--steps 128] [--prompt 1,263] [--stop 2]
 //               [--exec graph|fused|unfused] [--max-seq-len N] [--device 0]
+//               [--tokenizer tokenizer.model --text "a"]
 //
 // Prints the generated ids and "steps/s" like demo/main.cpp:70-72.
 #include <chrono>
@@ -21,7 +24,7 @@ static void usage() {
   std::fprintf(stderr,
                "usage: kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]\n"
                "       [--theta F] [--eps F] [--steps N] [--prompt id,id,...] [--stop id,id] [--exec graph|fused|unfused]\n"
-               "       [--max-seq-len N] [--device D]\n");
+               "       [--max-seq-len N] [--device D] [--tokenizer tokenizer.model --text \"...\"]\n");
 }
 
 int main(int argc, char** argv) {
@@ -34,6 +37,9 @@ int main(int argc, char** argv) {
   int steps = 128, exec = KH_EXEC_GRAPH;
   std::vector<int32_t> stop;  // is_sentence_ending ids (main.cpp:30): eos / <|eot_id|> / ...
   std::vector<int32_t> prompt{1, 263};  // BOS + "a": the reference demo's prompt (main.cpp:64)
+  const char* tok_path = nullptr;
+  std::string text;
+  bool have_text = false;
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&]() -> const char* {
@@ -49,6 +55,11 @@ int main(int argc, char** argv) {
     else if (a == "--theta") o.rope_theta = (float)std::atof(next());
     else if (a == "--eps") o.rms_eps = (float)std::atof(next());
     else if (a == "--steps") steps = std::atoi(next());
+    else if (a == "--tokenizer") tok_path = next();
+    else if (a == "--text") {
+      text = next();
+      have_text = true;
+    }
     else if (a == "--max-seq-len") o.max_seq_len = std::atoi(next());
     else if (a == "--device") o.device = std::atoi(next());
     else if (a == "--exec") {
@@ -69,6 +80,28 @@ int main(int argc, char** argv) {
       usage();
       return 2;
     }
+  }
+  kh_spm* tok = nullptr;
+  if (tok_path) {
+    const int trc = kh_spm_create_from_file(tok_path, &tok);
+    if (trc != KH_OK) {
+      std::fprintf(stderr, "tokenizer load failed: %d (%s)\n", trc, kh_error_string(trc));
+      return 1;
+    }
+    if (have_text) {  // model.cpp:158-165: BOS on for the Llama family; encode.cpp:37-41
+      int32_t n = 0;
+      prompt.assign(text.size() * 4 + 8, 0);
+      if (kh_spm_encode(tok, text.data(), (int64_t)text.size(), 1, 0, prompt.data(), (int32_t)prompt.size(),
+                        &n) != KH_OK) {
+        std::fprintf(stderr, "encode failed\n");
+        return 1;
+      }
+      prompt.resize((size_t)n);
+    }
+    if (stop.empty()) stop.push_back(kh_spm_eos_id(tok));  // is_sentence_ending, encode.cpp:48-51
+  } else if (have_text) {
+    std::fprintf(stderr, "--text needs --tokenizer\n");
+    return 2;
   }
   kh_model* m = nullptr;
   int rc = kh_model_create_from_file(path, &o, &m);
@@ -95,6 +128,13 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "generate failed: %d (%s)\n", rc, kh_error_string(rc));
     kh_model_destroy(m);
     return 1;
+  }
+  if (tok) {  // main.cpp:43-45: printf("%s ", model.decode(words))
+    std::vector<char> buf((size_t)n * 16 + 16);
+    int64_t len = 0;
+    if (kh_spm_decode(tok, words.data(), n, buf.data(), (int64_t)buf.size(), &len) == KH_OK)
+      std::printf("%.*s \n", (int)len, buf.data());
+    kh_spm_destroy(tok);
   }
   for (int i = 0; i < n; ++i) std::printf("%d ", words[i]);
   const double dur = std::chrono::duration<double>(t1 - t0).count();
