@@ -164,7 +164,9 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 // vmcnt(0) -> relaxed agent ticket; last arriver: agent acquire -> barrier -> reads), which is
 // placement-independent (splits of a head land on different XCDs) and never waits on another
 // workgroup, so it cannot hang.  The ticket counter is re-armed by the merger.
+#ifndef KH_ATTN_UB
 #define KH_ATTN_UB 4
+#endif
 #ifndef KH_ATTN_MIN_TS
 #define KH_ATTN_MIN_TS 256  // timesteps per split before a second split is opened
 #endif
