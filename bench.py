@@ -83,7 +83,7 @@ def timed_generate(m, steps, warmup, world, dev):
     return res["words"], wall, res["ev_ms"]
 
 
-def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s):
+def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=10.0):
     """Oracle (port of the reference CPU backend) on this host's cores, bounded sample.  Two
     matmul variants: (i) the oracle's own OpenMP row-parallel GEMV, (ii) the oracle
     with its fp32 matmuls routed through numpy's bundled OpenBLAS sgemv (the reference's
@@ -145,19 +145,23 @@ def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s):
         passes += 1
         if first_words is None:
             first_words = words
-        if time.perf_counter() - t0 > min(10.0, budget_s):
+        if time.perf_counter() - t0 > min(min_sample_s, budget_s):
             break
     dt = time.perf_counter() - t0
     words = first_words
     O.use_openblas(0)
-    match = words == list(gpu_words[:len(words)])
+    # token-for-token check on the common prefix of the CPU pass and the GPU's own greedy run from
+    # the same prompt (the GPU list is at least as long as the CPU pass, see measure())
+    n_cmp = min(len(words), len(gpu_words))
+    div = next((i for i in range(n_cmp) if words[i] != gpu_words[i]), None)
+    match = n_cmp > 0 and div is None
     how = ("fp32 matmuls via numpy's bundled OpenBLAS sgemv (the reference's Armadillo->BLAS path)"
            if variant == "openblas" else "OpenMP row-parallel fp32 GEMV")
     return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"{n} decode steps = {passes} pass(es) over the first {len(words)} steps of the "
                       f"same greedy decode ({spec.name}, prompt {PROMPT}), {how}, {dt:.1f}s",
             "variant": variant, "calibration_ms_per_token": calib,
-            "tokens_match_gpu": bool(match)}
+            "tokens_match_gpu": bool(match), "tokens_compared": n_cmp, "first_divergence": div}
 
 
 def load_traffic(kernel_key):
@@ -172,18 +176,79 @@ def load_traffic(kernel_key):
         return None
 
 
+def host_mem_available_gb() -> float:
+    """Host memory this process may still take: min(MemAvailable, cgroup limit - usage)."""
+    avail = float("inf")
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) / 1e6
+    except OSError:
+        pass
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        if mx != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail, (int(mx) - cur) / 1e9)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def cpu_extra_7b(spec_q8, img_q8_dev, local_rank, args):
+    """the reference has NO CPU int8 path (kernels_interfaces.cpp:54-61), so
+    the CPU comparison point for Llama-2-7B int8 is (i) CPU fp32 Llama-2-7B and (ii) the oracle's
+    own restated CPU int8 (cuda/matmul_kernel.cu:56-87 on the host), both clearly labelled."""
+    out = {}
+    dev = torch.device(f"cuda:{local_rank}")
+    half = max(4.0, args.cpu_budget_s / 3)
+    # (ii) restated CPU int8 on the very image the GPU ran
+    img_h = img_q8_dev.cpu().numpy()
+    try:
+        r = cpu_baseline(spec_q8, img_h, [], 16, half, min_sample_s=half)
+        out["cpu_int8_restated"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant")}
+        out["cpu_int8_restated"]["label"] = ("oracle restatement of cuda/matmul_kernel.cu:56-87 on the "
+                                             "host; the reference itself has no CPU int8")
+    finally:
+        del img_h
+    # (i) CPU fp32 Llama-2-7B: needs the 26.4 GB fp32 image on the host
+    s32 = binfmt.PRESETS["llama2-7b"]
+    need_gb = binfmt.image_nbytes(s32) / 1e9
+    have = host_mem_available_gb()
+    if have < need_gb + 8:
+        out["cpu_fp32"] = {"skipped": f"host memory {have:.0f} GB < {need_gb + 8:.0f} GB needed"}
+        return out
+    img32 = binfmt.synth_image(s32, seed=1234, device=dev)
+    torch.cuda.synchronize(dev)
+    img_h = img32.cpu().numpy()
+    del img32
+    torch.cuda.empty_cache()
+    try:
+        r = cpu_baseline(s32, img_h, [], 16, half, min_sample_s=half)
+        out["cpu_fp32"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant",
+                                             "calibration_ms_per_token")}
+        out["cpu_fp32"]["label"] = "reference-equivalent CPU fp32 path on Llama-2-7B (same shapes, fp32 weights)"
+    finally:
+        del img_h
+    return out
+
+
 def measure(spec, args, rank, world, local_rank, primary):
+    from kuiperllama_amd import replicas
     dev = torch.device(f"cuda:{local_rank}")
     m, img = build_model(spec, local_rank)
     words, wall, ev_ms = timed_generate(m, args.steps, args.warmup, world, dev)
     tok_s = world * args.steps / wall
     mean_pos = (args.steps - 1) / 2.0
     bytes_tok = spec.algorithmic_bytes_per_token(mean_pos)
+    # every replica's own rate (HIP events around its step loop), gathered for the spread
+    per = replicas.gather_per_replica(args.steps / (ev_ms * 1e-3), world, dev)
     out = {
         "value": tok_s, "ms_per_step": 1e3 * wall / args.steps, "hip_event_ms": ev_ms,
         "bytes_per_token": bytes_tok,
         "step_gbs": bytes_tok * (args.steps / wall) / 1e9,
         "words_head": words[:8],
+        "replicas": replicas.spread(per),
     }
     # SURVEY 8d extras, all outside the contract's timed region: repeated runs (median) and the
     # single-step latency at pos 0 / 64 / 127
@@ -195,28 +260,38 @@ def measure(spec, args, rank, world, local_rank, primary):
         allr = sorted(reps + [args.steps / (ev_ms * 1e-3)])
         out["runs"] = {"n": len(allr), "median_tok_s": allr[len(allr) // 2], "min_tok_s": allr[0],
                        "max_tok_s": allr[-1], "clock": "HIP events around the step loop, per replica"}
+    # the 128-step greedy run of the metric's definition (demo/main.cpp:69), untimed when --steps is
+    # smaller: source of the CPU token comparison and of the latency positions
+    ref_steps = max(args.steps, args.cpu_tokens, 128)
+    ref_words, ref_ms = (words, ev_ms) if ref_steps == args.steps else m.generate(PROMPT, ref_steps, exec="graph")
+    out["tok_s_128_steps"] = ref_steps / (ref_ms * 1e-3)
     lat = {}
     for p in (0, 64, 127):
-        if p < args.steps:
-            us = sorted(m.time_step(p, 9))
-            lat[str(p)] = round(us[len(us) // 2], 2)
+        us = sorted(m.time_step(p, 9))
+        lat[str(p)] = round(us[len(us) // 2], 2)
     out["latency_us_at_pos"] = lat
-    # prompt phase (extends the reference): 128 fed-only prompt tokens + 1 step, with
-    # the multi-token prefill and with the reference's one-token-per-step prompt phase
-    if args.steps >= 16:
+    # prompt phase (extends the reference): 128 fed-only prompt tokens, timed alone
+    # with HIP events on the model stream (kh_model_time_prefill)
+    if primary or args.prefill_secondary:
         rng = np.random.default_rng(0)
-        pp = [int(t) for t in rng.integers(0, spec.vocab_size, 129)]
+        pp = [int(t) for t in rng.integers(0, spec.vocab_size, 128)]
         pf = {}
-        for mode in ("1", "0"):
-            os.environ["KH_PREFILL"] = mode
-            m.generate(pp, len(pp), exec="graph")
-            pf[mode] = min(m.generate(pp, len(pp), exec="graph")[1] for _ in range(3))
-        os.environ.pop("KH_PREFILL", None)
-        out["prefill"] = {"prompt_tokens": len(pp) - 1,
-                          "prompt_tok_s": (len(pp) - 1) / (pf["1"] * 1e-3),
-                          "token_by_token_tok_s": (len(pp) - 1) / (pf["0"] * 1e-3),
-                          "speedup": pf["0"] / pf["1"],
-                          "note": "K/V rows bit-identical to the token-by-token prompt phase"}
+        for mode in ("gemm", "gemv", "token"):
+            try:
+                pf[mode] = min(m.time_prefill(pp, 0, mode) for _ in range(3))
+            except Exception as e:  # noqa: BLE001
+                pf[mode] = None
+                log(f"[bench] prefill mode {mode}: {e!r}")
+        out["prefill"] = {"prompt_tokens": len(pp)}
+        names = {"gemm": "mfma_gemm", "gemv": "b_token_gemv", "token": "token_by_token"}
+        for mode, ms in pf.items():
+            if ms:
+                out["prefill"][names[mode] + "_tok_s"] = len(pp) / (ms * 1e-3)
+        if pf.get("gemm") and pf.get("token"):
+            out["prefill"]["speedup_gemm_vs_token"] = pf["token"] / pf["gemm"]
+        out["prefill"]["note"] = ("mfma_gemm: fp32-MFMA GEMM, weights streamed once per 128 tokens, fp32 "
+                                  "tolerance vs the oracle; b_token_gemv: 8/4 tokens per weight pass on the "
+                                  "VALU, bit-identical to token_by_token (the reference's prompt phase)")
     # per-kernel durations measured live with HIP events on the model's stream.  The roofline
     # figure uses back-to-back launches of the kernel over all layers between two events (no
     # event between launches); "kernels_avg_us_evented" is the whole step with an event after
@@ -240,12 +315,19 @@ def measure(spec, args, rank, world, local_rank, primary):
                                               for n, v in b2b.items()), 1),
         "kernels_avg_us_evented": {n: round(v["avg_us"], 3) for n, v in prof.items()},
     }
-    if primary and rank == 0 and world == 1 and not args.no_cpu_baseline:
-        img_h = img.cpu().numpy()
-        out["cpu_baseline"] = cpu_baseline(spec, img_h, words, args.cpu_tokens, args.cpu_budget_s)
-        del img_h
     m.close()
-    del m, img
+    del m
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if primary:
+            img_h = img.cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(spec, img_h, ref_words, args.cpu_tokens, args.cpu_budget_s)
+            del img_h
+        elif spec.name == "llama2-7b-int8":
+            try:
+                out["cpu_baseline"] = cpu_extra_7b(spec, img, local_rank, args)
+            except Exception as e:  # noqa: BLE001  (the GPU numbers must still be reported)
+                out["cpu_baseline"] = {"error": repr(e)}
+    del img
     torch.cuda.empty_cache()
     return out
 
@@ -255,14 +337,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)  # generate(model, "a", 128), main.cpp:69
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="llama3.2-1b", choices=sorted(binfmt.PRESETS))
-    ap.add_argument("--secondary", default="llama2-7b-int8",
-                    help="second workload of the metric, measured in the same run ('' = none)")
+    ap.add_argument("--workload", default=None, choices=sorted(binfmt.PRESETS),
+                    help="default: llama3.2-1b on one GPU (BASELINE configs[1]); llama2-7b fp32 for "
+                         "N > 1 (configs[4]: independent replicas)")
+    ap.add_argument("--secondary", default=None,
+                    help="second workload of the metric, measured in the same run ('' = none; "
+                         "default llama2-7b-int8 on one GPU, none for N > 1)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="extra untimed-by-the-contract runs for the median (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=128)
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--prefill-secondary", action="store_true", default=True)
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -273,6 +359,10 @@ def main():
     rank, world, local_rank = replicas.init_from_env("nccl", torch.device(f"cuda:{local_rank}"))
     if world != args.gpus:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if args.workload is None:
+        args.workload = replicas.default_workload(world)
+    if args.secondary is None:
+        args.secondary = "llama2-7b-int8" if world == 1 else ""
 
     spec = binfmt.PRESETS[args.workload]
     res = measure(spec, args, rank, world, local_rank, primary=True)
@@ -286,8 +376,11 @@ def main():
                          "value": r2["value"], "unit": "tokens/s", "ms_per_step": r2["ms_per_step"],
                          "dtype": "int8 weights x f32 activations" if s2.quant else "f32",
                          "roofline": r2["roofline"], "runs": r2.get("runs"),
+                         "tok_s_128_steps": r2.get("tok_s_128_steps"),
                          "latency_us_at_pos": r2.get("latency_us_at_pos"),
                          "prefill": r2.get("prefill")}
+            if "cpu_baseline" in r2:
+                secondary["cpu_baseline"] = r2["cpu_baseline"]
         except Exception as e:  # the primary number must still be reported
             secondary = {"error": repr(e)}
 
@@ -298,14 +391,19 @@ def main():
             "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 weights x f32 activations" if spec.quant else "f32",
-            "data": "synthetic (seeded random weights in the reference .bin layout)",
+            "data": "synthetic via kuiperllama_amd.binfmt.synth_image (seeded torch RNG on the GPU, the "
+                    "reference exporter's .bin byte layout and init std; not the reference exporter itself)",
             "config": {"workload": f"{spec.name} greedy decode, batch 1, prompt {PROMPT}, "
                                    f"{args.steps} steps from pos 0 (demo/main.cpp generate)",
-                       "parallelism": f"replicas{world} (no shard, no collective)",
+                       "parallelism": f"replicas{world} (no shard, no data-path collective; one process "
+                                      f"per GPU, HIP_VISIBLE_DEVICES/LOCAL_RANK pinning)",
+                       "timing_backend": replicas.backend_in_use(world),
                        "exec": "hipGraph replay, 5L+2 fused HIP kernels per token",
                        "kv_cache_rows": spec.seq_len},
             "roofline": res["roofline"],
-            "runs": res.get("runs"), "latency_us_at_pos": res.get("latency_us_at_pos"),
+            "replicas": res["replicas"],
+            "runs": res.get("runs"), "tok_s_128_steps": res.get("tok_s_128_steps"),
+            "latency_us_at_pos": res.get("latency_us_at_pos"),
             "prefill": res.get("prefill"),
         }
         if "cpu_baseline" in res:

@@ -227,6 +227,14 @@ int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prom
  * geometries outside the mirrored kernels (head_size <= 32, dim > 4096, merged launch). */
 int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
 
+/* Duration (ms, HIP events on the model stream) of the prompt phase alone for n fed-only tokens:
+ * KH_PREFILL_TOKEN = the reference's prompt phase, one forward pass per token (demo/main.cpp:20-22)
+ * replayed from the decode hipGraph; KH_PREFILL_GEMV = kh_model_prefill's bit-identical B-token
+ * kernels; KH_PREFILL_GEMM = the fp32-MFMA GEMM prefill.  Leaves the K/V rows of those positions. */
+enum { KH_PREFILL_TOKEN = 0, KH_PREFILL_GEMV = 1, KH_PREFILL_GEMM = 2 };
+int kh_model_time_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0,
+                          int32_t mode, float* h_ms);
+
 /* Average duration of ONE kernel class launched back to back (no event between launches, so
  * no event overhead in the figure): the kernel is captured for layers 0..L-1 `reps` times into
  * a hipGraph that is replayed between two HIP events on the model stream (cls / sample: `reps`

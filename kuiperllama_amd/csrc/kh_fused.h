@@ -33,10 +33,13 @@ template <bool QUANT>
 __device__ __forceinline__ float* lds_red_ptr(f32x4* xs, int M) {
   return (float*)(xs + (QUANT ? 4 * ((M >> 4) + 1) : (M >> 2)));
 }
-// xs | red[KH_WAVES_MAX] | comb[2*KH_WAVES_MAX] (split-row partial sums)
-static inline size_t fused_lds_bytes(bool quant, int M) {
-  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 3 * KH_WAVES_MAX * sizeof(float);
+// xs | red[KH_WAVES_MAX] | comb[2*KH_WAVES_MAX] (split-row partial sums) | argmax idx[KH_WAVES_MAX]
+// (cls) | scale slabs [waves][SP][2][64] (int8 scale prefetch, kh_gemv.h)
+static inline size_t fused_lds_bytes(bool quant, int M, int sp = 0, int wg = KH_WG_MAX) {
+  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 4 * KH_WAVES_MAX * sizeof(float) +
+         (size_t)(wg / KH_WAVE) * sp * 2 * KH_WAVE * sizeof(float);
 }
+__device__ __forceinline__ float* lds_scale_ptr(float* red) { return red + 4 * KH_WAVES_MAX; }
 
 // Three-way select on VALUES.  Written as `w == 0 ? a : ...` directly on named variables, the
 // conditional operator yields an lvalue, clang selects between the variables' ADDRESSES, and the
@@ -79,7 +82,7 @@ struct KhQkvArgs {
 
 // MERGED: this stage shares its launch with its consumers: results leave with write-through
 // (sc1) stores and every workgroup-iteration arrives on its KV group's counter.
-template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED>
+template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED, int SP = 0>
 __device__ __forceinline__ void qkv_body(const KhQkvArgs& a, char* smem_raw, int vb, int vgrid,
                                          const KhSync& sync) {
   // Every kernel argument used inside the lambdas is first copied into a scalar local: a
@@ -192,13 +195,14 @@ __device__ __forceinline__ void qkv_body(const KhQkvArgs& a, char* smem_raw, int
     if (cnt && threadIdx.x == 0)
       __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre, [&]() __attribute__((always_inline)) { st.issue(); },
-                              [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi, vb, vgrid, after);
+  gemv_pairs<QUANT, U, SPLIT, SP>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre, [&]() __attribute__((always_inline)) { st.issue(); },
+                                  [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi, vb, vgrid, after,
+                                  lds_scale_ptr(red));
 }
-template <bool QUANT, int U, int MAXV, int SPLIT>
+template <bool QUANT, int U, int MAXV, int SPLIT, int SP = 0>
 __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  qkv_body<QUANT, U, MAXV, SPLIT, false>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x, KhSync{});
+  qkv_body<QUANT, U, MAXV, SPLIT, false, SP>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x, KhSync{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -265,7 +269,7 @@ struct KhGemvResArgs {
 // MERGED: the input vector is produced earlier in the same launch (attention output): the first
 // weight chunk and the residual are fetched FIRST, then the workgroup waits (bounded) for the
 // producers' counter and stages the vector with sc1 loads.
-template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED>
+template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED, int SP = 0>
 __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem_raw, int vb,
                                               int vgrid, const KhSync& sync) {
   // scalar locals for everything the lambdas touch (see qkv_body)
@@ -291,7 +295,7 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem
     x[2 * p] = r.x0 + s0;
     x[2 * p + 1] = r.x1 + s1;
   };
-  gemv_pairs<QUANT, U, SPLIT>(
+  gemv_pairs<QUANT, U, SPLIT, SP>(
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) {
 #if !KH_EXP_NOSTAGE
@@ -309,13 +313,13 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem
         st.finish(xs, 0.f, red);
 #endif
       },
-      epi, vb, vgrid);
+      epi, vb, vgrid, NoAfter(), lds_scale_ptr(red));
 }
-template <bool QUANT, int U, int MAXV, int SPLIT>
+template <bool QUANT, int U, int MAXV, int SPLIT, int SP = 0>
 __global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  gemv_res_body<QUANT, U, MAXV, SPLIT, false>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x,
-                                              KhSync{});
+  gemv_res_body<QUANT, U, MAXV, SPLIT, false, SP>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x,
+                                                  KhSync{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,7 +331,7 @@ struct KhFfn13Args {
   int dim, hidden, gshift;
   float eps;
 };
-template <bool QUANT, int U, int MAXV>
+template <bool QUANT, int U, int MAXV, int SP = 0>
 __global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -339,9 +343,10 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
   auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane == 0) a.h[r] = swiglu1(s0, s1);
   };
-  gemv_pairs<QUANT, U, 1>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<QUANT, U, 1, SP>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
-                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
+                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi,
+                       (int)blockIdx.x, (int)gridDim.x, NoAfter(), lds_scale_ptr(red));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,7 +360,7 @@ struct KhClsArgs {
   int dim, vocab, gshift;
   float eps;
 };
-template <bool QUANT, int U, int MAXV>
+template <bool QUANT, int U, int MAXV, int SP = 0>
 __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -379,10 +384,11 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
       amax_merge(bv, bi, s1, r1);
     }
   };
-  gemv_pairs<QUANT, U, 1>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
+  gemv_pairs<QUANT, U, 1, SP>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
                           [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
-                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
+                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi,
+                       (int)blockIdx.x, (int)gridDim.x, NoAfter(), lds_scale_ptr(red));
   // stage-1 argmax: one partial per workgroup (ties -> lowest index)
   int* redi = (int*)(red + 3 * KH_WAVES_MAX);
   __syncthreads();
@@ -399,8 +405,8 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
     a.part_idx[blockIdx.x] = i;
   }
 }
-static inline size_t cls_lds_bytes(bool quant, int M) {
-  return fused_lds_bytes(quant, M) + KH_WAVES_MAX * sizeof(int);
+static inline size_t cls_lds_bytes(bool quant, int M, int sp = 0, int wg = KH_WG_MAX) {
+  return fused_lds_bytes(quant, M, sp, wg);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -76,6 +76,7 @@ struct kh_model {
   // launch geometry
   struct Shape {
     int u = 2, split = 1, grid = 1, wg = KH_WG;
+    int sp = 0;  // int8 scale-prefetch depth (kh_gemv.h): 0 = scales loaded beside the weights
   };
   Shape sh_qkv, sh_wo, sh_ffn, sh_w2, sh_cls;
   // graph
@@ -163,6 +164,21 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
   return sh;
 }
 
+// int8 scale prefetch (kh_gemv.h, SP): usable when the group size is the exporter's 64, a wave's
+// column range spans at most 64 groups and the shape gives every wave at most `spn` row pairs.
+// KH_Q8_SP=0 switches it off (A/B measurements).
+int pick_sp(bool quant, int gshift, const kh_model::Shape& sh, int pairs, int M, int spn) {
+  if (!quant || gshift != 6) return 0;
+  if (const char* e = getenv("KH_Q8_SP"))
+    if (e[0] == '0') return 0;
+  const int ppw = (sh.wg / KH_WAVE) / sh.split;
+  const int iters = (pairs + sh.grid * ppw - 1) / (sh.grid * ppw);
+  const int Mc = M / 16;
+  const int Q = (((Mc + sh.split - 1) / sh.split) + 3) & ~3;
+  if (Q > 4 * KH_WAVE) return 0;
+  return iters <= spn ? spn : 0;
+}
+
 int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
   int s = 0;
@@ -174,54 +190,72 @@ int ilog2_exact(int v) {
 // Template dispatch.  U: 16-byte loads per row in flight per lane; MV: in-register staging depth
 // (kh_stage_maxv of the input length); SP: waves sharing one row pair.
 // The workgroup size comes from a variable `kh_launch_wg` in scope at the dispatch site.
-#define KH_L3(KERNEL, Q, UU, MV, GRID, LDS, STREAM, ARGS) \
-  hipLaunchKernelGGL((KERNEL<Q, UU, MV>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
-#define KH_L4(KERNEL, Q, UU, MV, SP, GRID, LDS, STREAM, ARGS) \
-  hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
-#define KH_SEL_MV3(KERNEL, Q, UU, MV, ...)                  \
+// SPN: the scale-prefetch depth this kernel class is instantiated with (kh_gemv.h, int8 only);
+// used when the launch shape asks for it (`kh_launch_sp` in scope), else the SP = 0 kernel.
+#define KH_L3(KERNEL, SPN, Q, UU, MV, GRID, LDS, STREAM, ARGS)                                    \
+  do {                                                                                            \
+    if ((Q) && kh_launch_sp == (SPN))                                                             \
+      hipLaunchKernelGGL((KERNEL<Q, UU, MV, ((Q) ? (SPN) : 0)>), dim3(GRID), dim3(kh_launch_wg),  \
+                         LDS, STREAM, ARGS);                                                      \
+    else                                                                                          \
+      hipLaunchKernelGGL((KERNEL<Q, UU, MV, 0>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM,     \
+                         ARGS);                                                                   \
+  } while (0)
+#define KH_L4(KERNEL, SPN, Q, UU, MV, SP, GRID, LDS, STREAM, ARGS)                                \
+  do {                                                                                            \
+    if ((Q) && kh_launch_sp == (SPN))                                                             \
+      hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP, ((Q) ? (SPN) : 0)>), dim3(GRID),                  \
+                         dim3(kh_launch_wg), LDS, STREAM, ARGS);                                  \
+    else                                                                                          \
+      hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP, 0>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, \
+                         ARGS);                                                                   \
+  } while (0)
+#define KH_SEL_MV3(KERNEL, SPN, Q, UU, MV, ...)             \
   do {                                                      \
     if ((MV) == 4)                                          \
-      KH_L3(KERNEL, Q, UU, 4, __VA_ARGS__);                 \
+      KH_L3(KERNEL, SPN, Q, UU, 4, __VA_ARGS__);            \
     else                                                    \
-      KH_L3(KERNEL, Q, UU, 0, __VA_ARGS__);                 \
+      KH_L3(KERNEL, SPN, Q, UU, 0, __VA_ARGS__);            \
   } while (0)
-#define KH_SEL_SP4(KERNEL, Q, UU, MV, SP, ...)              \
+#define KH_SEL_SP4(KERNEL, SPN, Q, UU, MV, SP, ...)         \
   do {                                                      \
     if ((SP) == 4)                                          \
-      KH_L4(KERNEL, Q, UU, MV, 4, __VA_ARGS__);             \
+      KH_L4(KERNEL, SPN, Q, UU, MV, 4, __VA_ARGS__);        \
     else if ((SP) == 2)                                     \
-      KH_L4(KERNEL, Q, UU, MV, 2, __VA_ARGS__);             \
+      KH_L4(KERNEL, SPN, Q, UU, MV, 2, __VA_ARGS__);        \
     else                                                    \
-      KH_L4(KERNEL, Q, UU, MV, 1, __VA_ARGS__);             \
+      KH_L4(KERNEL, SPN, Q, UU, MV, 1, __VA_ARGS__);        \
   } while (0)
-#define KH_SEL_MV4(KERNEL, Q, UU, MV, SP, ...)              \
+#define KH_SEL_MV4(KERNEL, SPN, Q, UU, MV, SP, ...)         \
   do {                                                      \
     if ((MV) == 4)                                          \
-      KH_SEL_SP4(KERNEL, Q, UU, 4, SP, __VA_ARGS__);        \
+      KH_SEL_SP4(KERNEL, SPN, Q, UU, 4, SP, __VA_ARGS__);   \
     else                                                    \
-      KH_SEL_SP4(KERNEL, Q, UU, 0, SP, __VA_ARGS__);        \
+      KH_SEL_SP4(KERNEL, SPN, Q, UU, 0, SP, __VA_ARGS__);   \
   } while (0)
-#define KH_SEL_U(SEL, KERNEL, QUANT, U, ...)                \
+#define KH_SEL_U(SEL, KERNEL, SPN, QUANT, U, ...)           \
   do {                                                      \
     if (QUANT) {                                            \
       if ((U) >= 4)                                         \
-        SEL(KERNEL, true, 4, __VA_ARGS__);                  \
+        SEL(KERNEL, SPN, true, 4, __VA_ARGS__);             \
       else                                                  \
-        SEL(KERNEL, true, 2, __VA_ARGS__);                  \
+        SEL(KERNEL, SPN, true, 2, __VA_ARGS__);             \
     } else {                                                \
       if ((U) >= 8)                                         \
-        SEL(KERNEL, false, 8, __VA_ARGS__);                 \
+        SEL(KERNEL, SPN, false, 8, __VA_ARGS__);            \
       else if ((U) >= 4)                                    \
-        SEL(KERNEL, false, 4, __VA_ARGS__);                 \
+        SEL(KERNEL, SPN, false, 4, __VA_ARGS__);            \
       else                                                  \
-        SEL(KERNEL, false, 2, __VA_ARGS__);                 \
+        SEL(KERNEL, SPN, false, 2, __VA_ARGS__);            \
     }                                                       \
   } while (0)
 // kernels without / with the SPLIT parameter
-#define KH_DISPATCH3(KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS) \
-  KH_SEL_U(KH_SEL_MV3, KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS)
-#define KH_DISPATCH4(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
-  KH_SEL_U(KH_SEL_MV4, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
+#define KH_DISPATCH3(KERNEL, SPN, QUANT, U, MV, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV3, KERNEL, SPN, QUANT, U, MV, GRID, LDS, STREAM, ARGS)
+#define KH_DISPATCH4(KERNEL, SPN, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV4, KERNEL, SPN, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
+#define KH_SPN_LAYER 4  // per-layer GEMVs: up to 4 row pairs per wave
+#define KH_SPN_CLS 8    // classifier: up to 8
 
 KhQkvArgs fill_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -250,9 +284,9 @@ void launch_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const KhQkvArgs a = fill_qkv(m, l);
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_qkv.wg;
-  KH_DISPATCH4(k_qkv, qn, m->sh_qkv.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_qkv.split, m->sh_qkv.grid,
-               fused_lds_bytes(qn, c.dim), m->stream, a);
+  const int kh_launch_wg = m->sh_qkv.wg, kh_launch_sp = m->sh_qkv.sp;
+  KH_DISPATCH4(k_qkv, KH_SPN_LAYER, qn, m->sh_qkv.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_qkv.split,
+               m->sh_qkv.grid, fused_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
 }
 KhAttnArgs fill_attn(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -305,9 +339,9 @@ void launch_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const KhGemvResArgs a = fill_wo(m, l);
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_wo.wg;
-  KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_wo.split, m->sh_wo.grid,
-               fused_lds_bytes(qn, c.dim), m->stream, a);
+  const int kh_launch_wg = m->sh_wo.wg, kh_launch_sp = m->sh_wo.sp;
+  KH_DISPATCH4(k_gemv_res, KH_SPN_LAYER, qn, m->sh_wo.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_wo.split,
+               m->sh_wo.grid, fused_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
 }
 void launch_ffn13(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -323,9 +357,9 @@ void launch_ffn13(kh_model* m, int l) {
   a.gshift = m->gshift;
   a.eps = c.rms_eps;
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_ffn.wg;
-  KH_DISPATCH3(k_ffn13, qn, m->sh_ffn.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_ffn.grid,
-               fused_lds_bytes(qn, c.dim), m->stream, a);
+  const int kh_launch_wg = m->sh_ffn.wg, kh_launch_sp = m->sh_ffn.sp;
+  KH_DISPATCH3(k_ffn13, KH_SPN_LAYER, qn, m->sh_ffn.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_ffn.grid,
+               fused_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
 }
 void launch_w2(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -337,9 +371,9 @@ void launch_w2(kh_model* m, int l) {
   a.K = c.dim;
   a.gshift = m->gshift;
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_w2.wg;
-  KH_DISPATCH4(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split, m->sh_w2.grid,
-               fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
+  const int kh_launch_wg = m->sh_w2.wg, kh_launch_sp = m->sh_w2.sp;
+  KH_DISPATCH4(k_gemv_res, KH_SPN_LAYER, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split,
+               m->sh_w2.grid, fused_lds_bytes(qn, c.hidden_dim, kh_launch_sp, kh_launch_wg), m->stream, a);
 }
 void launch_cls(kh_model* m) {
   const kh_config& c = m->cfg;
@@ -356,9 +390,9 @@ void launch_cls(kh_model* m) {
   a.eps = c.rms_eps;
   // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_cls.wg;
-  KH_DISPATCH3(k_cls, qn, m->sh_cls.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_cls.grid, cls_lds_bytes(qn, c.dim),
-               m->stream, a);
+  const int kh_launch_wg = m->sh_cls.wg, kh_launch_sp = m->sh_cls.sp;
+  KH_DISPATCH3(k_cls, KH_SPN_CLS, qn, m->sh_cls.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_cls.grid,
+               cls_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
 }
 void launch_sample(kh_model* m, int advance, int n_forced) {
   const kh_config& c = m->cfg;
@@ -774,6 +808,11 @@ int finish_create(kh_model* m) {
   m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS",
                          c.is_quant ? KH_WG : KH_WG_MAX, KH_WG_MAX);
   m->nparts = m->sh_cls.grid;
+  m->sh_qkv.sp = pick_sp(c.is_quant, m->gshift, m->sh_qkv, (c.dim + 2 * c.kv_dim) / 2, c.dim, KH_SPN_LAYER);
+  m->sh_wo.sp = pick_sp(c.is_quant, m->gshift, m->sh_wo, c.dim / 2, c.dim, KH_SPN_LAYER);
+  m->sh_ffn.sp = pick_sp(c.is_quant, m->gshift, m->sh_ffn, c.hidden_dim, c.dim, KH_SPN_LAYER);
+  m->sh_w2.sp = pick_sp(c.is_quant, m->gshift, m->sh_w2, c.dim / 2, c.hidden_dim, KH_SPN_LAYER);
+  m->sh_cls.sp = pick_sp(c.is_quant, m->gshift, m->sh_cls, (c.vocab_size + 1) / 2, c.dim, KH_SPN_CLS);
   m->n_sync = c.layer_num * (c.kv_head_num + KH_SYNC_REPL) * KH_SYNC_STRIDE;
   KH_CHECK_HIP(hipMalloc((void**)&m->sync_words, sizeof(int) * (size_t)(m->n_sync + 1)));
   KH_CHECK_HIP(hipMemsetAsync(m->sync_words, 0, sizeof(int) * (size_t)(m->n_sync + 1), m->stream));
@@ -790,6 +829,7 @@ int finish_create(kh_model* m) {
         m->sh_qkv.wg == KH_WG && m->sh_wo.wg == KH_WG)
       m->merge_combo = merged_combo_id(c.is_quant, m->sh_qkv.u, m->sh_qkv.split,
                                        attn_group_lanes(c), m->sh_wo.u, m->sh_wo.split);
+    if (m->merge_combo >= 0) m->sh_qkv.sp = m->sh_wo.sp = 0;  // the merged launch has no SP form
   }
   m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
   // attention: 8 waves per (head, split) shorten each lane's timestep loop; the merged launch
@@ -842,12 +882,18 @@ int finish_create(kh_model* m) {
     KH_CHECK_HIP(hipMemcpy(m->cos_cache, hc_.data(), n * sizeof(float), hipMemcpyHostToDevice));
   }
   // big activation vectors (hidden > 16 K floats) need the >64 KiB dynamic-LDS opt-in
-  const size_t lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim);
+  size_t lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim, m->sh_w2.sp, m->sh_w2.wg);
+  if (lds_need > 160 * 1024 && m->sh_w2.sp) {
+    m->sh_w2.sp = 0;
+    lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim, 0, m->sh_w2.wg);
+  }
   if (lds_need > 160 * 1024) return KH_ERR_UNSUPPORTED;
   if (lds_need > 64 * 1024) {
     const int v = (int)lds_need;
 #define KH_ATTR(Q, UU, SP)                                                                     \
-  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP>,                             \
+  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP, 0>,                          \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, v);                    \
+  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP, ((Q) ? KH_SPN_LAYER : 0)>,   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, v)
     KH_ATTR(false, 8, 1); KH_ATTR(false, 8, 2); KH_ATTR(false, 8, 4);
     KH_ATTR(false, 4, 1); KH_ATTR(false, 4, 2); KH_ATTR(false, 4, 4);
@@ -1264,6 +1310,56 @@ extern "C" int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n,
   for (int t0 = 0; t0 < n; t0 += B)
     launch_prefill_chunk(m, h_tokens + t0, n - t0 < B ? n - t0 : B, pos0 + t0, B);
   return kh_launch_status();
+}
+
+// Time the prompt phase alone: n fed-only tokens at positions pos0.., HIP events on the model
+// stream around exactly that work (no decode step, no set_state).  mode KH_PREFILL_TOKEN = the
+// reference's one forward pass per prompt token (demo/main.cpp:20-22), replayed from the hipGraph;
+// KH_PREFILL_GEMV = kh_model_prefill's B-token VALU kernels; KH_PREFILL_GEMM = the MFMA GEMM path.
+extern "C" int kh_model_time_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0,
+                                     int32_t mode, float* h_ms) {
+  if (!m || !h_tokens || !h_ms || n <= 0 || pos0 < 0) return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if ((int64_t)pos0 + n > c.cache_len) return KH_ERR_RANGE;
+  for (int i = 0; i < n; ++i)
+    if (h_tokens[i] < 0 || h_tokens[i] >= c.vocab_size) return KH_ERR_RANGE;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  int rc;
+  if (mode == KH_PREFILL_TOKEN) {
+    if ((rc = ensure_seq_cap(m, pos0 + n + 1)) != KH_OK) return rc;
+    std::vector<int32_t> forced((size_t)m->seq_cap + 1, -1);
+    for (int i = 0; i < n; ++i) forced[pos0 + i] = h_tokens[i];
+    forced[pos0 + n] = h_tokens[n - 1];  // keeps the last timed step in the prompt phase
+    KH_CHECK_HIP(hipMemcpyAsync(m->d_forced, forced.data(), forced.size() * sizeof(int32_t),
+                                hipMemcpyHostToDevice, m->stream));
+    KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    const int n_forced = m->seq_cap + 1;
+    if ((rc = ensure_graph(m, n_forced)) != KH_OK) return rc;
+    set_state(m, h_tokens[0], pos0);
+    KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+    for (int s = 0; s < n;) {
+      if (n - s >= KH_GRAPH_STEPS) {
+        KH_CHECK_HIP(hipGraphLaunch(m->gexecN, m->stream));
+        s += KH_GRAPH_STEPS;
+      } else {
+        KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
+        s += 1;
+      }
+    }
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+  } else if (mode == KH_PREFILL_GEMV) {
+    if (!prefill_supported(m)) return KH_ERR_UNSUPPORTED;
+    if ((rc = ensure_prefill_buffers(m)) != KH_OK) return rc;
+    KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+    if ((rc = kh_model_prefill(m, h_tokens, n, pos0)) != KH_OK) return rc;
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+  } else {
+    return KH_ERR_UNSUPPORTED;
+  }
+  KH_CHECK_HIP(hipEventSynchronize(m->ev1));
+  KH_CHECK_HIP(hipEventElapsedTime(h_ms, m->ev0, m->ev1));
+  if ((rc = kh_launch_status()) != KH_OK) return rc;
+  return check_sync_err(m);
 }
 
 extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,

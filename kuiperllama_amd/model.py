@@ -143,6 +143,19 @@ class KuiperModel:
         _ffi.check(_ffi.lib().kh_model_prefill(self._h, t, len(tokens), pos0), "kh_model_prefill")
         torch.cuda.synchronize()
 
+    PREFILL_MODES = {"token": 0, "gemv": 1, "gemm": 2}
+
+    def time_prefill(self, tokens: Sequence[int], pos0: int = 0, mode: str = "gemm") -> float:
+        """Milliseconds (HIP events on the model stream) of the prompt phase alone for `tokens`:
+        "token" = one forward pass per token (the reference), "gemv" = B-token VALU kernels,
+        "gemm" = fp32-MFMA GEMM prefill."""
+        t = (C.c_int32 * len(tokens))(*[int(x) for x in tokens])
+        ms = C.c_float(0.0)
+        _ffi.check(_ffi.lib().kh_model_time_prefill(self._h, t, len(tokens), pos0,
+                                                    self.PREFILL_MODES[mode], C.byref(ms)),
+                   "kh_model_time_prefill")
+        return float(ms.value)
+
     def time_step(self, pos: int, reps: int = 9) -> List[float]:
         """Microseconds of one graph-replayed decode step at `pos`, `reps` samples."""
         us = (C.c_float * reps)()

@@ -13,6 +13,25 @@ from typing import Callable, Tuple
 import torch
 
 
+# BASELINE.json config 5: the 8-GPU number is Llama-2-7B fp32, one independent replica per GPU
+# (the reference pins device 0, llama3.cpp:118); N = 1 is configs[1].
+REPLICA_WORKLOAD = "llama2-7b"
+SINGLE_WORKLOAD = "llama3.2-1b"
+
+
+def default_workload(world: int) -> str:
+    """Workload bench.py measures when --workload is not given."""
+    return REPLICA_WORKLOAD if world > 1 else SINGLE_WORKLOAD
+
+
+def backend_in_use(world: int) -> str:
+    """Collective backend the timing protocol actually runs on ("none" for one process)."""
+    if world <= 1:
+        return "none"
+    import torch.distributed as dist
+    return str(dist.get_backend()) if dist.is_initialized() else "uninitialised"
+
+
 def init_from_env(backend: str, device: torch.device | None = None) -> Tuple[int, int, int]:
     """-> (rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
     rank = int(os.environ.get("RANK", "0"))
@@ -63,6 +82,26 @@ def timed_replica_run(run: Callable[[], float | None], steps: int, world: int,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     return wall, world * steps / wall
+
+
+def gather_per_replica(value: float, world: int, device: torch.device) -> list:
+    """Every rank's `value` (its own wall seconds, tok/s ...), in rank order, on every rank.
+    Measurement plumbing only - the data path exchanges nothing."""
+    if world <= 1:
+        return [float(value)]
+    import torch.distributed as dist
+    red_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([value], dtype=torch.float64, device=red_dev)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def spread(per_replica: list) -> dict:
+    """min / max / relative spread of per-replica throughputs."""
+    lo, hi = min(per_replica), max(per_replica)
+    return {"per_replica": [round(v, 3) for v in per_replica], "min": lo, "max": hi,
+            "spread_frac": (hi - lo) / hi if hi > 0 else 0.0}
 
 
 def shutdown(world: int) -> None:

@@ -33,6 +33,9 @@ GOLDEN_MODELS = ["ref_llama_gqa_tied", "ref_llama_mha_untied", "ref_qwen_bias_in
 def oracle():
     from oracle import oracle as O
     O.build()
+    # nproc can be a lie inside a cgroup (256 logical CPUs seen, 16 granted): an OpenMP team sized
+    # by nproc thrashes, so size it by what the process may really use
+    O.set_threads(max(1, min(O.effective_cpus(), 32)))
     return O
 
 

@@ -43,7 +43,10 @@ def _worker(rank, world, port, q):
         time.sleep(0.05 * (rank + 1))  # uneven replicas: the max must win
 
     wall, agg = replicas.timed_replica_run(run, 16, w, torch.device("cpu"), lambda: None)
-    q.put((rank, wall, agg, out["words"]))
+    own = 16 / (0.05 * (rank + 1))  # a per-replica figure that differs by rank
+    per = replicas.gather_per_replica(own, w, torch.device("cpu"))
+    q.put((rank, wall, agg, out["words"], per, replicas.backend_in_use(w),
+           replicas.default_workload(w)))
     replicas.shutdown(w)
 
 
@@ -60,7 +63,13 @@ def test_two_replicas_gloo():
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    (r0, w0, a0, words0), (r1, w1, a1, words1) = res
+    (r0, w0, a0, words0, per0, be0, wl0), (r1, w1, a1, words1, per1, be1, wl1) = res
+    # N > 1 measures BASELINE config 5 (Llama-2-7B fp32 replicas) and reports every replica
+    assert wl0 == wl1 == "llama2-7b" and be0 == be1 == "gloo"
+    assert per0 == per1 and len(per0) == world and per0[0] == 2 * per0[1]
+    from kuiperllama_amd import replicas
+    sp = replicas.spread(per0)
+    assert sp["min"] == per0[1] and sp["max"] == per0[0] and abs(sp["spread_frac"] - 0.5) < 1e-12
     assert words0 == words1 and len(words0) == 16   # replicas decode the same tokens
     assert w0 == w1                                  # max over ranks is shared
     assert w0 >= 0.1                                 # the slower replica (0.1 s sleep) dominates
@@ -73,6 +82,8 @@ def test_single_process_path_needs_no_process_group():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         os.environ.pop(k, None)
     assert replicas.init_from_env("gloo") == (0, 1, 0)
+    assert replicas.default_workload(1) == "llama3.2-1b" and replicas.backend_in_use(1) == "none"
+    assert replicas.gather_per_replica(3.5, 1, torch.device("cpu")) == [3.5]
     wall, agg = replicas.timed_replica_run(lambda: None, 10, 1, torch.device("cpu"), lambda: None)
     assert wall > 0 and abs(agg - 10 / wall) < 1e-6
     replicas.shutdown(1)
