@@ -71,6 +71,12 @@ int kh_matmul_q8(const float* x, const int8_t* w8, const float* scales, int32_t 
 int kh_embedding_f32(const int32_t* tokens, int32_t n_tokens, const float* w, float* out,
                      int32_t dim, int32_t vocab, void* stream);
 
+/* The same with the token ids in HOST memory, which is what the reference's EmbeddingKernel
+ * receives (the input tensor is a CPU tensor, op/embedding.cpp; emb_kernel.cu:25-29 uploads it per
+ * call).  The ids travel in the kernel arguments, 64 per launch: no staging buffer, no copy. */
+int kh_embedding_f32_host(const int32_t* h_tokens, int32_t n_tokens, const float* w, float* out,
+                          int32_t dim, int32_t vocab, void* stream);
+
 /* SwigluKernel (kernels_interface.h:19-20; cuda/swiglu_kernel.cu:4-47):
  * out = a*sigmoid(a) * b ; out may alias a (llama3.cpp:708). */
 int kh_swiglu_f32(const float* a, const float* b, float* out, int32_t n, void* stream);

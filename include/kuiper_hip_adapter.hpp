@@ -1,18 +1,27 @@
-// kuiper_hip_adapter.hpp — header-only C++ glue that exposes libkuiper_hip.so with the
-// SIGNATURES of KuiperLLama's kernel function pointers
+// kuiper_hip_adapter.hpp — header-only C++ glue that exposes libkuiper_hip.so with EXACTLY the
+// signatures of KuiperLLama's kernel function pointers
 //   (kuiper/source/op/kernels/kernels_interface.h:6-44)
-// so that a `kDeviceHIP` branch in kuiper/source/op/kernels/kernels_interfaces.cpp:21-132 is a
-// one-line-per-op change.
+// and getters shaped like kernel::get_*_kernel (kernels_interface.h:48-68,
+// kernels_interfaces.cpp:21-132), so that a `kDeviceHIP` branch in those getters is one line per op
+// (INTEGRATION.md).
 //
-// It is a template over the tensor type so it compiles both against the reference's
-// tensor::Tensor (kuiper/include/tensor/tensor.h:12-95: ptr<T>(), get_dim(), dims_size(), size())
-// and against the tiny stand-in used by this repo's tests — the reference headers pull in
-// glog/armadillo/CUDA which do not exist in this build environment.
+// Kernels<Tensor, Config, DeviceType> is a template over the three reference types that appear in
+// the typedefs:
+//   Tensor      tensor::Tensor            (kuiper/include/tensor/tensor.h:12-95: ptr<T>(), get_dim(),
+//                                          size())
+//   Config      kernel::CudaConfig        (kuiper/include/base/cuda_config.h:6-13: `.stream`)
+//   DeviceType  base::DeviceType          (kuiper/include/base/base.h:35-39, enum class : uint8_t)
+// With those three plugged in, every static member below IS a value of the matching typedef:
+// tests/cpp/test_ref_binding.cpp includes the reference's own kernels_interface.h and
+// static_asserts std::is_same for all eleven, then drives real tensor::Tensor objects through the
+// getters on the GPU.  tests/cpp/test_adapter.cpp instantiates the same template with a stand-in
+// Tensor so the op tests also run where /root/reference does not exist (the GPU box).
 //
 // Error behaviour: the reference's kernels are `void` and CHECK-abort on precondition failures.
 // The adapter keeps `void` signatures and routes a non-zero C-ABI status to a user-replaceable
 // handler (default: print + abort, i.e. the reference's LOG(FATAL) semantics).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -35,11 +44,13 @@ inline void check(int code, const char* what) {
 }
 
 // Runtime replacements for the reference's compile-time switches:
-//   LLAMA3_SUPPORT -> {KH_ROPE_HALF, eps 1e-5}; QWEN2_SUPPORT -> {KH_ROPE_HALF, eps 1e-6};
-//   neither -> {KH_ROPE_INTERLEAVED, eps 1e-5}.
+//   LLAMA3_SUPPORT -> {KH_ROPE_HALF, eps 1e-5, theta 5e5}; QWEN2_SUPPORT -> {KH_ROPE_HALF, eps 1e-6,
+//   theta 1e6}; neither -> {KH_ROPE_INTERLEAVED, eps 1e-5, theta 1e4}
+//   (cpu/rope_kernel.cpp:3-16,43,83; cpu/rmsnorm_kernel.cpp:24-28).
 struct Flavor {
   int32_t rope_mode = KH_ROPE_INTERLEAVED;
   float rms_eps = 1e-5f;
+  float rope_theta = 10000.0f;
 };
 inline Flavor& flavor() {
   static Flavor f;
@@ -51,74 +62,87 @@ struct HipConfig {
   void* stream = nullptr;
 };
 
-template <class Tensor>
+template <class Tensor, class Config = HipConfig, class DeviceType = int>
 struct Kernels {
+  // the eleven typedefs of kernels_interface.h:6-44, spelled over the template parameters
+  using AddKernel = void (*)(const Tensor&, const Tensor&, const Tensor&, void*);
+  using MatmulKernel = void (*)(const Tensor&, const Tensor&, const Tensor&, float, const Config*);
+  using MatmulKernelQuant = void (*)(const Tensor&, const Tensor&, const Tensor&, int32_t,
+                                     const Tensor&, const Config*);
+  using EmbeddingKernel = void (*)(const Tensor&, const Tensor&, const Tensor&, int32_t, void*);
+  using SwigluKernel = void (*)(const Tensor&, const Tensor&, const Tensor&, void*);
+  using MHAKernel = void (*)(int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t,
+                             const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                             const Tensor&, DeviceType, Config*);
+  using RMSNormKernel = void (*)(const Tensor&, const Tensor&, const Tensor&, void*);
+  using RoPEKernel = void (*)(int32_t, int32_t, int32_t, const Tensor&, const Tensor&,
+                              const Tensor&, const Tensor&, const Tensor&, void*);
+  using ScaleKernel = void (*)(float, const Tensor&, void*);
+  using SoftmaxInplaceKernel = void (*)(const Tensor&, void*);
+  using ScaleSumKernel = void (*)(const Tensor&, const Tensor&, const Tensor&, int, int, int, void*);
+
+  template <class T>
+  static T* mut(const Tensor& t) {  // the reference passes outputs as const Tensor& too
+    return const_cast<T*>(t.template ptr<T>());
+  }
+  static void* stream_of(const Config* c) { return c ? (void*)c->stream : nullptr; }
+
   // AddKernel (kernels_interface.h:6-7)
   static void add(const Tensor& in1, const Tensor& in2, const Tensor& out, void* stream) {
-    check(kh_add_f32(in1.template ptr<float>(), in2.template ptr<float>(),
-                     const_cast<float*>(out.template ptr<float>()), (int32_t)in1.size(), stream),
+    check(kh_add_f32(in1.template ptr<float>(), in2.template ptr<float>(), mut<float>(out),
+                     (int32_t)in1.size(), stream),
           "kh_add_f32");
   }
   // MatmulKernel (kernels_interface.h:9-10): weight [K, M] row-major, input [M]
-  template <class Config>
   static void matmul(const Tensor& input, const Tensor& weight, const Tensor& output, float scale,
                      const Config* config) {
     const int32_t K = weight.get_dim(0), M = weight.get_dim(1);
     check(kh_matmul_f32(input.template ptr<float>(), weight.template ptr<float>(),
-                        const_cast<float*>(output.template ptr<float>()), M, K, scale,
-                        config ? (void*)config->stream : nullptr),
+                        mut<float>(output), M, K, scale, stream_of(config)),
           "kh_matmul_f32");
   }
   // MatmulKernelQuant (kernels_interface.h:12-14)
-  template <class Config>
   static void matmul_quant8(const Tensor& input, const Tensor& weight, const Tensor& output,
                             int32_t group_size, const Tensor& scale, const Config* config) {
     const int32_t K = weight.get_dim(0), M = weight.get_dim(1);
     check(kh_matmul_q8(input.template ptr<float>(), weight.template ptr<int8_t>(),
-                       scale.template ptr<float>(), group_size,
-                       const_cast<float*>(output.template ptr<float>()), M, K,
-                       config ? (void*)config->stream : nullptr),
+                       scale.template ptr<float>(), group_size, mut<float>(output), M, K,
+                       stream_of(config)),
           "kh_matmul_q8");
   }
-  // EmbeddingKernel (kernels_interface.h:16-17).  The reference hands a HOST token tensor and
-  // uploads it inside the kernel launcher (cuda/emb_kernel.cu:25-29); `d_tokens` is the caller's
-  // device staging buffer for that upload (>= n tokens), which keeps the ABI allocation-free.
-  static void embedding(const Tensor& h_tokens, const Tensor& weight, const Tensor& output,
-                        int32_t vocab_size, void* stream, int32_t* d_tokens,
-                        int (*h2d)(void* dst, const void* src, size_t n, void* stream)) {
-    const int32_t n = (int32_t)h_tokens.size();
-    check(h2d(d_tokens, h_tokens.template ptr<int32_t>(), sizeof(int32_t) * (size_t)n, stream),
-          "token upload");
-    check(kh_embedding_f32(d_tokens, n, weight.template ptr<float>(),
-                           const_cast<float*>(output.template ptr<float>()), weight.get_dim(1),
-                           vocab_size, stream),
-          "kh_embedding_f32");
+  // EmbeddingKernel (kernels_interface.h:16-17).  `input` is the HOST tensor of token ids the
+  // reference hands over (emb_kernel.cu:25-29 uploads it per call); the ids go to the GPU in the
+  // kernel arguments (kh_embedding_f32_host), so nothing is staged or owned here.
+  static void embedding(const Tensor& input, const Tensor& weight, const Tensor& output,
+                        int32_t vocab_size, void* stream) {
+    check(kh_embedding_f32_host(input.template ptr<int32_t>(), (int32_t)input.size(),
+                                weight.template ptr<float>(), mut<float>(output),
+                                weight.get_dim(1), vocab_size, stream),
+          "kh_embedding_f32_host");
   }
   // SwigluKernel (kernels_interface.h:19-20)
   static void swiglu(const Tensor& in1, const Tensor& in2, const Tensor& out, void* stream) {
-    check(kh_swiglu_f32(in1.template ptr<float>(), in2.template ptr<float>(),
-                        const_cast<float*>(out.template ptr<float>()), (int32_t)in1.size(), stream),
+    check(kh_swiglu_f32(in1.template ptr<float>(), in2.template ptr<float>(), mut<float>(out),
+                        (int32_t)in1.size(), stream),
           "kh_swiglu_f32");
   }
-  // MHAKernel (kernels_interface.h:22-28)
-  template <class Config>
+  // MHAKernel (kernels_interface.h:22-28); device_type is what the reference's mha_kernel uses to
+  // pick its inner CPU/CUDA helpers (cpu/mha_kernel.cpp:25-57) - there is only one device here
   static void mha(int32_t pos, int32_t head_num, int32_t layer_index, int32_t seq_len,
                   int32_t kv_dim, int32_t kv_mul, int32_t head_size, const Tensor& mha_out,
                   const Tensor& query, const Tensor& score, const Tensor& key_cache,
-                  const Tensor& value_cache, int /*device_type*/, Config* config) {
+                  const Tensor& value_cache, DeviceType /*device_type*/, Config* config) {
     check(kh_mha_f32(nullptr, pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
-                     const_cast<float*>(mha_out.template ptr<float>()),
-                     query.template ptr<float>(), const_cast<float*>(score.template ptr<float>()),
+                     mut<float>(mha_out), query.template ptr<float>(), mut<float>(score),
                      key_cache.template ptr<float>(), value_cache.template ptr<float>(),
-                     config ? (void*)config->stream : nullptr),
+                     stream_of(config)),
           "kh_mha_f32");
   }
   // RMSNormKernel (kernels_interface.h:30-31)
   static void rmsnorm(const Tensor& input, const Tensor& weight, const Tensor& output,
                       void* stream) {
     check(kh_rmsnorm_f32(input.template ptr<float>(), weight.template ptr<float>(),
-                         const_cast<float*>(output.template ptr<float>()), (int32_t)input.size(),
-                         flavor().rms_eps, stream),
+                         mut<float>(output), (int32_t)input.size(), flavor().rms_eps, stream),
           "kh_rmsnorm_f32");
   }
   // RoPEKernel (kernels_interface.h:33-36): input_pos is a HOST int32 tensor in the reference
@@ -127,18 +151,18 @@ struct Kernels {
                    const Tensor& input_k, const Tensor& input_pos, const Tensor& sin_cache,
                    const Tensor& cos_cache, void* stream) {
     const int32_t pos = *input_pos.template ptr<int32_t>();
-    check(kh_rope_f32(dim, kv_dim, head_size, const_cast<float*>(input_q.template ptr<float>()),
-                      const_cast<float*>(input_k.template ptr<float>()), nullptr, pos,
-                      sin_cache.template ptr<float>(), cos_cache.template ptr<float>(),
+    check(kh_rope_f32(dim, kv_dim, head_size, mut<float>(input_q), mut<float>(input_k), nullptr,
+                      pos, sin_cache.template ptr<float>(), cos_cache.template ptr<float>(),
                       flavor().rope_mode, stream),
           "kh_rope_f32");
   }
-  // sin_cos_cache_calc_cu (cuda/rope_kernel.cuh:9-10); theta is an #ifdef in the reference
-  static void sin_cos_cache_calc(int head_size, int max_seq_len, float theta,
-                                 const Tensor& sin_cache, const Tensor& cos_cache, void* stream) {
-    check(kh_sincos_cache_f32(head_size, max_seq_len, theta,
-                              const_cast<float*>(sin_cache.template ptr<float>()),
-                              const_cast<float*>(cos_cache.template ptr<float>()), stream),
+  // sin_cos_cache_calc_cu (cuda/rope_kernel.cuh:9-10); Stream = cudaStream_t in the reference.
+  // theta is an #ifdef there (cuda/rope_kernel.cu:124-151), flavor().rope_theta here.
+  template <class Stream>
+  static void sin_cos_cache_calc(int head_size, int max_seq_len, const Tensor& sin_cache,
+                                 const Tensor& cos_cache, Stream stream) {
+    check(kh_sincos_cache_f32(head_size, max_seq_len, flavor().rope_theta, mut<float>(sin_cache),
+                              mut<float>(cos_cache), (void*)stream),
           "kh_sincos_cache_f32");
   }
   // argmax_kernel_cu (cuda/argmax_kernel.cuh:4)
@@ -149,22 +173,31 @@ struct Kernels {
   }
   // CPU-only helpers of the reference (kernels_interface.h:38-44), available on device here
   static void scale(float s, const Tensor& input, void* stream) {
-    check(kh_scale_f32(s, const_cast<float*>(input.template ptr<float>()), (int32_t)input.size(),
-                       stream),
-          "kh_scale_f32");
+    check(kh_scale_f32(s, mut<float>(input), (int32_t)input.size(), stream), "kh_scale_f32");
   }
   static void softmax_inplace(const Tensor& input, void* stream) {
-    check(kh_softmax_f32(const_cast<float*>(input.template ptr<float>()), (int32_t)input.size(),
-                         stream),
-          "kh_softmax_f32");
+    check(kh_softmax_f32(mut<float>(input), (int32_t)input.size(), stream), "kh_softmax_f32");
   }
   static void scale_sum(const Tensor& value, const Tensor& scale_t, const Tensor& output, int t,
                         int size, int stride, void* stream) {
     check(kh_scale_sum_f32(value.template ptr<float>(), scale_t.template ptr<float>(),
-                           const_cast<float*>(output.template ptr<float>()), t, size, stride,
-                           stream),
+                           mut<float>(output), t, size, stride, stream),
           "kh_scale_sum_f32");
   }
+
+  // kernel::get_*_kernel(base::DeviceType::kDeviceHIP) (kernels_interfaces.cpp:21-132): what each
+  // getter returns for the new enumerator
+  static AddKernel get_add_kernel() { return &Kernels::add; }
+  static EmbeddingKernel get_emb_kernel() { return &Kernels::embedding; }
+  static MatmulKernel get_matmul_kernel() { return &Kernels::matmul; }
+  static MatmulKernelQuant get_matmul_kernel_quant8() { return &Kernels::matmul_quant8; }
+  static MHAKernel get_mha_kernel() { return &Kernels::mha; }
+  static RMSNormKernel get_rmsnorm_kernel() { return &Kernels::rmsnorm; }
+  static RoPEKernel get_rope_kernel() { return &Kernels::rope; }
+  static ScaleKernel get_scale_kernel() { return &Kernels::scale; }
+  static SoftmaxInplaceKernel get_softmax_kernel() { return &Kernels::softmax_inplace; }
+  static SwigluKernel get_swiglu_kernel() { return &Kernels::swiglu; }
+  static ScaleSumKernel get_scale_sum_kernel() { return &Kernels::scale_sum; }
 };
 
 }  // namespace kuiper_hip

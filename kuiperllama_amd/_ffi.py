@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("KH_LIB") or os.path.join(_PKG, "lib", "libkuiper_hip.
 # every symbol include/kuiper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "kh_error_string", "kh_version", "kh_device_count",
-    "kh_add_f32", "kh_matmul_f32", "kh_matmul_q8", "kh_embedding_f32", "kh_swiglu_f32",
+    "kh_add_f32", "kh_matmul_f32", "kh_matmul_q8", "kh_embedding_f32", "kh_embedding_f32_host", "kh_swiglu_f32",
     "kh_rmsnorm_f32", "kh_rope_f32", "kh_sincos_cache_f32", "kh_mha_f32", "kh_mha_decode_f32",
     "kh_mha_decode_workspace_bytes", "kh_argmax_f32",
     "kh_argmax_f32_host", "kh_softmax_f32", "kh_scale_f32", "kh_scale_sum_f32",
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     L.kh_matmul_f32.argtypes = [_vp, _vp, _vp, _i32, _i32, _f32, _vp]
     L.kh_matmul_q8.argtypes = [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]
     L.kh_embedding_f32.argtypes = [_vp, _i32, _vp, _vp, _i32, _i32, _vp]
+    L.kh_embedding_f32_host.argtypes = [_vp, _i32, _vp, _vp, _i32, _i32, _vp]
     L.kh_swiglu_f32.argtypes = [_vp, _vp, _vp, _i32, _vp]
     L.kh_rmsnorm_f32.argtypes = [_vp, _vp, _vp, _i32, _f32, _vp]
     L.kh_rope_f32.argtypes = [_i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]

@@ -75,8 +75,8 @@ def build_adapter_test(force: bool = False) -> str:
     """C++ host-side test of include/kuiper_hip_adapter.hpp, linked against the C-ABI .so."""
     build_lib()
     inc = os.path.normpath(os.path.join(_PKG, "..", "include"))
-    deps = [ADAPTER_TEST_SRC, os.path.join(inc, "kuiper_hip_adapter.hpp"),
-            os.path.join(inc, "kuiper_hip.h"), LIB_PATH]
+    deps = [ADAPTER_TEST_SRC, os.path.join(os.path.dirname(ADAPTER_TEST_SRC), "adapter_cases.hpp"),
+            os.path.join(inc, "kuiper_hip_adapter.hpp"), os.path.join(inc, "kuiper_hip.h"), LIB_PATH]
     if (not force and os.path.exists(ADAPTER_TEST_BIN)
             and all(os.path.getmtime(d) <= os.path.getmtime(ADAPTER_TEST_BIN) for d in deps)):
         return ADAPTER_TEST_BIN
@@ -101,3 +101,19 @@ def build_demo(force: bool = False) -> str:
     subprocess.check_call([_hipcc(), "-std=c++17", "-O2", f"-I{inc}", DEMO_SRC, "-o", DEMO_BIN,
                            f"-L{LIB_DIR}", "-lkuiper_hip", "-Wl,-rpath,$ORIGIN"])
     return DEMO_BIN
+
+
+REF_ROOT = os.environ.get("KUIPER_REF", "/root/reference")
+REF_BINDING_BIN = os.path.normpath(os.path.join(_PKG, "..", "oracle", "_ref", "test_ref_binding"))
+
+
+def build_ref_binding() -> str | None:
+    """tests/cpp/test_ref_binding.cpp against the reference's REAL headers and tensor sources
+    (oracle/Makefile `ref`): only where the reference checkout exists; the binary lands in
+    oracle/_ref/ (git-ignored) and travels to the GPU box.  Returns None without a checkout."""
+    if not os.path.isdir(os.path.join(REF_ROOT, "kuiper", "include")):
+        return REF_BINDING_BIN if os.path.exists(REF_BINDING_BIN) else None
+    build_lib()
+    subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
+                           "ref", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
+    return REF_BINDING_BIN

@@ -276,6 +276,46 @@ extern "C" int kh_embedding_f32(const int32_t* tokens, int32_t n_tokens, const f
   return kh_launch_status();
 }
 
+// The reference hands the embedding kernel a HOST tensor of token ids and uploads it per call
+// (cuda/emb_kernel.cu:25-29: clone + cudaMalloc + cudaMemcpy).  Here the ids of up to
+// KH_EMB_BATCH tokens travel BY VALUE in the kernel arguments: no staging buffer, no H2D copy,
+// nothing to own, and the launch stays graph-capturable; longer token lists take several launches.
+#define KH_EMB_BATCH 64
+struct KhEmbTokens {
+  int32_t t[KH_EMB_BATCH];
+};
+__global__ __launch_bounds__(KH_WG) void k_embedding_args(const KhEmbTokens tk,
+                                                          const float* __restrict__ w,
+                                                          float* __restrict__ out, int dim,
+                                                          int vocab, int vec_ok) {
+  const int t = blockIdx.x;
+  const int token = tk.t[t];
+  if (token < 0 || token >= vocab) return;
+  const float* src = w + (size_t)token * dim;
+  float* dst = out + (size_t)t * dim;
+  if (vec_ok) {
+    const f32x4* s4 = (const f32x4*)src;
+    f32x4* d4 = (f32x4*)dst;
+    for (int i = threadIdx.x; i < (dim >> 2); i += KH_WG) d4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < dim; i += KH_WG) dst[i] = src[i];
+  }
+}
+extern "C" int kh_embedding_f32_host(const int32_t* h_tokens, int32_t n_tokens, const float* w,
+                                     float* out, int32_t dim, int32_t vocab, void* stream) {
+  if (!h_tokens || !w || !out || n_tokens <= 0 || dim <= 0 || vocab <= 0)
+    return KH_ERR_INVALID_ARG;
+  const int vec = (dim % 4 == 0) && kh_aligned16(w) && kh_aligned16(out);
+  for (int t0 = 0; t0 < n_tokens; t0 += KH_EMB_BATCH) {
+    const int n = n_tokens - t0 < KH_EMB_BATCH ? n_tokens - t0 : KH_EMB_BATCH;
+    KhEmbTokens tk;
+    for (int i = 0; i < KH_EMB_BATCH; ++i) tk.t[i] = i < n ? h_tokens[t0 + i] : -1;
+    hipLaunchKernelGGL(k_embedding_args, dim3(n), dim3(KH_WG), 0, (hipStream_t)stream, tk, w,
+                       out + (size_t)t0 * dim, dim, vocab, vec);
+  }
+  return kh_launch_status();
+}
+
 // =============================================================================================
 // rmsnorm.  reference: cuda/rmsnorm_kernel.cu:5-50 (1 block x 128 thr, rsqrtf); arithmetic here
 // follows the CPU backend (cpu/rmsnorm_kernel.cpp:24-32): 1/sqrt, then w * (r * x).

@@ -1,0 +1,29 @@
+// TEST-ONLY stand-in for the CUDA runtime headers the reference's host sources include.  The ten
+// runtime calls made by tensor.cpp / alloc.cpp / alloc_cu.cpp / cuda_config.h are forwarded to the
+// HIP runtime, so the reference's own allocator and tensor class own MI355X memory inside
+// tests/cpp/test_ref_binding.cpp.  Not part of the product (which has no CUDA spelling anywhere).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>  // the real header brings it in; base/alloc.cpp calls std::memcpy / std::memset
+typedef ihipStream_t CUstream_st;  // alloc.cpp:14 spells the stream struct
+typedef hipStream_t cudaStream_t;
+typedef hipError_t cudaError_t;
+constexpr hipError_t cudaSuccess = hipSuccess;
+enum cudaMemcpyKind {
+  cudaMemcpyHostToHost = 0, cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2,
+  cudaMemcpyDeviceToDevice = 3
+};
+inline hipMemcpyKind refstub_kind(cudaMemcpyKind k) { return (hipMemcpyKind)(int)k; }
+inline cudaError_t cudaMalloc(void** p, size_t n) { return hipMalloc(p, n); }
+inline cudaError_t cudaFree(void* p) { return hipFree(p); }
+inline cudaError_t cudaGetDevice(int* d) { return hipGetDevice(d); }
+inline cudaError_t cudaSetDevice(int d) { return hipSetDevice(d); }
+inline cudaError_t cudaMemcpy(void* d, const void* s, size_t n, cudaMemcpyKind k) { return hipMemcpy(d, s, n, refstub_kind(k)); }
+inline cudaError_t cudaMemcpyAsync(void* d, const void* s, size_t n, cudaMemcpyKind k, cudaStream_t st = nullptr) { return hipMemcpyAsync(d, s, n, refstub_kind(k), st); }
+inline cudaError_t cudaMemset(void* p, int v, size_t n) { return hipMemset(p, v, n); }
+inline cudaError_t cudaMemsetAsync(void* p, int v, size_t n, cudaStream_t st = nullptr) { return hipMemsetAsync(p, v, n, st); }
+inline cudaError_t cudaDeviceSynchronize() { return hipDeviceSynchronize(); }
+inline cudaError_t cudaStreamDestroy(cudaStream_t s) { return hipStreamDestroy(s); }
+inline cudaError_t cudaStreamCreate(cudaStream_t* s) { return hipStreamCreate(s); }
+inline cudaError_t cudaGetLastError() { return hipGetLastError(); }

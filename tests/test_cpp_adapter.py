@@ -26,6 +26,35 @@ def test_adapter_compiles_and_links_without_gpu():
 def test_adapter_reference_op_tests_on_gpu(gpu):
     r = _run()
     assert r.returncode == 0 and "OK adapter tests passed" in r.stdout, r.stdout + r.stderr
+    assert "OK 13/13 operator entry points" in r.stdout
+
+
+def test_adapter_binds_to_reference_typedefs():
+    """tests/cpp/test_ref_binding.cpp includes the reference's own kernels_interface.h and
+    tensor.h and static_asserts std::is_same between the adapter's function types and all eleven
+    kernel typedefs; building it IS the check (kernels_interface.h:6-68).  Without a GPU the
+    binary stops after the getter wiring check (exit 77)."""
+    import torch
+    if not os.path.isdir(os.path.join(build.REF_ROOT, "kuiper", "include")):
+        pytest.skip("no reference checkout on this box (the binary is prebuilt where there is one)")
+    exe = build.build_ref_binding()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 77 and "static_asserts passed" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_tensor_class_through_adapter_on_gpu(gpu):
+    """The prebuilt oracle/_ref/test_ref_binding: real tensor::Tensor objects, allocated by the
+    reference's own CUDADeviceAllocator, through the thirteen get_*_kernel entry points."""
+    exe = build.build_ref_binding()
+    if not exe or not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_ref_binding was not built (needs the reference checkout)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK 13/13" in r.stdout, r.stdout + r.stderr
+    assert "reference tensor::Tensor + kernels_interface.h typedefs bound" in r.stdout
 
 
 @pytest.mark.gpu
