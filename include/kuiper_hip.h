@@ -36,8 +36,7 @@ enum {
   KH_ERR_IO = -3,          /* file open/map failure (reference: error::PathNotValid) */
   KH_ERR_FORMAT = -4,      /* malformed .bin (reference: error::ModelParseError) */
   KH_ERR_NO_DEVICE = -5,
-  KH_ERR_RANGE = -6,       /* token / position out of range */
-  KH_ERR_SYNC = -7         /* an in-launch hand-off timed out (results of that run are invalid) */
+  KH_ERR_RANGE = -6        /* token / position out of range */
 };
 const char* kh_error_string(int code);
 int kh_version(void);
@@ -142,13 +141,6 @@ int kh_scale_sum_f32(const float* value, const float* scale, float* out, int32_t
  * per-token forward, greedy generate loop captured in a hipGraph. */
 typedef struct kh_model kh_model;
 
-enum {
-  /* EXPERIMENTAL, off by default: run [qkv | attention | wo] of a layer as ONE launch with
-   * in-launch sc1/counter hand-offs (csrc/kh_merged.h) instead of three launches.  Bitwise
-   * identical results; measured neutral on Llama-3.2-1B fp32 (1009 vs 1010 tok/s) and -3 %
-   * on Llama-2-7B int8: a hand-off costs what a kernel boundary costs. */
-  KH_FLAG_MERGE = 2
-};
 typedef struct kh_model_opts {
   int32_t family;      /* KH_FAMILY_* : weight layout (llama3.cpp:290-423 / qwen2.cpp) */
   int32_t is_quant;    /* int8 group-quantised image (tools/export.py version 3) */
@@ -157,7 +149,7 @@ typedef struct kh_model_opts {
   float rms_eps;       /* 1e-5 / 1e-6 (QWEN2) */
   int32_t max_seq_len; /* rows of KV cache + sin/cos to allocate; 0 = header seq_len */
   int32_t device;      /* HIP device ordinal (reference: cudaSetDevice(0)) */
-  int32_t flags;       /* KH_FLAG_* */
+  int32_t flags;       /* reserved, 0 */
 } kh_model_opts;
 
 typedef struct kh_config {
@@ -166,8 +158,7 @@ typedef struct kh_config {
   int32_t family, rope_mode, cache_len;
   float rope_theta, rms_eps;
   int64_t weight_bytes; /* bytes of the weight arena resident in HBM */
-  int32_t merged_launch; /* 1: [qkv|attention|wo] run as one launch (kh_merged.h) */
-  int32_t launches_per_token;
+  int32_t launches_per_token; /* 5 per layer + classifier + sampler */
 } kh_config;
 
 /* Model::read_model_file + init (model.cpp:41-123, llama3.cpp:107-145) */
@@ -230,7 +221,7 @@ int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prom
  * tokens per pass over the weights, no logits.  Leaves the K/V cache rows pos0..pos0+n-1 BIT-IDENTICAL to n calls of
  * kh_model_predict(.., is_prompt = 1, KH_EXEC_FUSED).  kh_model_generate* use it for the
  * fed-only part of prompts of 3+ tokens (env KH_PREFILL=0 disables).  KH_ERR_UNSUPPORTED for
- * geometries outside the mirrored kernels (head_size <= 32, dim > 4096, merged launch). */
+ * geometries outside the mirrored kernels (head_size <= 32, dim > 4096). */
 int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
 
 /* Duration (ms, HIP events on the model stream) of the prompt phase alone for n fed-only tokens:

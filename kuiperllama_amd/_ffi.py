@@ -49,8 +49,7 @@ class Config(C.Structure):
         "dim", "hidden_dim", "layer_num", "head_num", "kv_head_num", "vocab_size", "seq_len",
         "kv_dim", "kv_mul", "head_size", "is_shared_weight", "is_quant", "group_size", "family",
         "rope_mode", "cache_len")] + [("rope_theta", C.c_float), ("rms_eps", C.c_float),
-                                      ("weight_bytes", C.c_int64), ("merged_launch", C.c_int32),
-                                      ("launches_per_token", C.c_int32)]
+                                      ("weight_bytes", C.c_int64), ("launches_per_token", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

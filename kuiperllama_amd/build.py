@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkuiper_hip.so")
 SOURCES = ["kh_ops.hip", "kh_model.hip", "kh_tokenizer.cpp"]
-HEADERS = ["kh_common.h", "kh_gemv.h", "kh_attn.h", "kh_fused.h", "kh_merged.h", "kh_prefill.h",
+HEADERS = ["kh_common.h", "kh_gemv.h", "kh_attn.h", "kh_fused.h", "kh_prefill.h",
            "../../include/kuiper_hip.h"]
 ARCH = "gfx950"
 
@@ -43,19 +43,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
+    objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
                # no implicit FMA contraction: results must not depend on which kernel a stage is
-               # inlined into (merged vs stand-alone launches are compared bit for bit) and the
+               # inlined into (decode vs B-token prefill kernels are compared bit for bit) and the
                # CPU oracle is built the same way; explicit __builtin_fmaf calls stay FMAs
                "-ffp-contract=off",
                "-Wno-unused-function", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))  # the translation units compile side by side
         objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -218,19 +218,11 @@ __host__ __device__ static inline AttnSplitWs attn_ws_carve(void* ws, int heads,
 
 // Attention of head h over timesteps [t_begin, t_end): leaves, for threads tid < hs, the
 // unnormalised output r = sum_t exp(s_t - M) v_t[tid] and L = sum_t exp(s_t - M); returns M.
-// SC1: q and cache row `fresh_t` were written earlier in the SAME launch with sc1 stores by other
-// workgroups (merged qkv|attention launch): read those with sc1 loads; older rows are plain.
-// WAIT: called exactly once by every thread (it may contain a barrier) after the plain loads of
-// the first batch are in flight and before anything produced by this launch is read.
-struct AttnNoWait {
-  __device__ __forceinline__ void operator()() const {}
-};
-template <int G, bool SC1, class WaitFn>
+template <int G>
 __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float* k_base,
                                                    const float* v_base, int kv_stride, int hs,
-                                                   int t_begin, int t_end, int fresh_t,
-                                                   float* smem, float& r_out, float& L_out,
-                                                   WaitFn&& WAIT) {
+                                                   int t_begin, int t_end, float* smem,
+                                                   float& r_out, float& L_out) {
   static_assert(G == 16 || G == 32 || G == 64, "G must be 16, 32 or 64");
   const int TPI = kh_wg() / G;
   float* red = smem;          // [8]
@@ -248,33 +240,19 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   f32x4 q4 = zero4;
   float m = -INFINITY, l = 0.f;
   f32x4 o = zero4;
-  bool first = true;  // every thread runs the body at least once: WAIT may hold a barrier
+  bool first = true;  // q is fetched behind the first batch of K/V rows (one memory round trip)
   for (int tb = t_begin + tg; first || tb < t_end; tb += TPI * KH_ATTN_UB) {
     f32x4 kv[KH_ATTN_UB], vv[KH_ATTN_UB];
 #pragma unroll
-    for (int u = 0; u < KH_ATTN_UB; ++u) {  // rows of earlier steps: plain loads, issued first
+    for (int u = 0; u < KH_ATTN_UB; ++u) {
       const int t = tb + u * TPI;
       const int tt = t < t_end ? t : t_end - 1;
-      if (!(SC1 && tt == fresh_t)) {
-        kv[u] = active ? K4[(size_t)tt * stride4 + dl] : zero4;
-        vv[u] = active ? V4[(size_t)tt * stride4 + dl] : zero4;
-      }
+      kv[u] = active ? K4[(size_t)tt * stride4 + dl] : zero4;
+      vv[u] = active ? V4[(size_t)tt * stride4 + dl] : zero4;
     }
     if (first) {
-      WAIT();
-      q4 = active ? (SC1 ? ld4_sc1((const f32x4*)q_h + dl) : ((const f32x4*)q_h)[dl]) : zero4;
+      q4 = active ? ((const f32x4*)q_h)[dl] : zero4;
       first = false;
-    }
-    if (SC1) {
-#pragma unroll
-      for (int u = 0; u < KH_ATTN_UB; ++u) {  // the row this launch produced: sc1 loads
-        const int t = tb + u * TPI;
-        const int tt = t < t_end ? t : t_end - 1;
-        if (tt == fresh_t) {
-          kv[u] = active ? ld4_sc1(K4 + (size_t)tt * stride4 + dl) : zero4;
-          vv[u] = active ? ld4_sc1(V4 + (size_t)tt * stride4 + dl) : zero4;
-        }
-      }
     }
 #pragma unroll
     for (int u = 0; u < KH_ATTN_UB; ++u) {
@@ -367,14 +345,12 @@ __device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h,
 }
 
 // One workgroup = (head h, split s) of a grid of heads*NS workgroups.  ws may be null iff NS==1.
-// Returns true in the workgroup that wrote the head's final output.  SC1: see attn_fast_partial;
-// the output then also leaves with sc1 stores (consumed by the wo stage of the same launch).
-template <int G, bool SC1 = false, class WaitFn = AttnNoWait>
+// Returns true in the workgroup that wrote the head's final output.
+template <int G>
 __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const float* k_base,
                                                       const float* v_base, int kv_stride, int hs,
                                                       int pos, float* out_h, float* smem, int h,
-                                                      int s, int NS, AttnSplitWs ws,
-                                                      WaitFn&& WAIT = WaitFn(), int NSW = 0) {
+                                                      int s, int NS, AttnSplitWs ws, int NSW = 0) {
   if (NSW <= 0) NSW = NS;  // slot stride of the workspace (>= NS)
   const int tid = threadIdx.x;
   const int nT = pos + 1;
@@ -384,15 +360,10 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
   const int t_begin = s * TS;
   const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
   float r, L;
-  const float M = attn_fast_partial<G, SC1>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end,
-                                            pos, smem, r, L, WAIT);
+  const float M = attn_fast_partial<G>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end, smem,
+                                       r, L);
   if (nact == 1) {
-    if (tid < hs) {
-      if (SC1)
-        st_sc1(out_h + tid, r / L);
-      else
-        out_h[tid] = r / L;
-    }
+    if (tid < hs) out_h[tid] = r / L;
     return true;
   }
   // ---- publish this split's partial, take a ticket ---------------------------------------
@@ -416,11 +387,7 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
   if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
   if (tid < hs) {
-    const float v = attn_merge_splits(ws, h, tid, hs, nact, NSW);
-    if (SC1)
-      st_sc1(out_h + tid, v);
-    else
-      out_h[tid] = v;
+    out_h[tid] = attn_merge_splits(ws, h, tid, hs, nact, NSW);
   }
   if (tid == 0) __hip_atomic_store(&ws.cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
@@ -634,11 +601,10 @@ __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem
   const int s = b / (a.kv_heads * a.kv_mul);
   const int h = g * a.kv_mul + j;
   const size_t head_off = (size_t)g * a.head_size;
-  attn_head_decode_fast<G, false>(
+  attn_head_decode_fast<G>(
       a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
       a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, smem, h, s, a.nsplit,
-      attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), AttnNoWait{},
-      a.ws_stride);
+      attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), a.ws_stride);
 }
 
 // KVM = 0: per-head workgroups only.  KVM = kv_mul > 1: per-head workgroups at short contexts,

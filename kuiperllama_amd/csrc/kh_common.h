@@ -40,55 +40,6 @@ __device__ __forceinline__ T ld_nt(const T* p) {
   return __builtin_nontemporal_load(p);
 }
 
-// ---- write-through / cache-bypassing accesses for in-launch hand-offs (guide G16, recipe R1) --
-// Producer: sc1 stores (agent-scope relaxed atomics lower to global_store ... sc1) -> every
-// storing wave s_waitcnt vmcnt(0) -> barrier -> ONE lane bumps an agent-scope counter.
-// Consumer: one lane polls the counter (relaxed, s_sleep between polls, BOUNDED), barrier, then
-// reads the payload with sc1 loads.  No fences needed on either side.
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_sc1(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x4 ld4_sc1(const f32x4* p) {
-  const unsigned long long* q = (const unsigned long long*)p;
-  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  f32x4 r;
-  r.x = __builtin_bit_cast(float, (unsigned)(a & 0xffffffffu));
-  r.y = __builtin_bit_cast(float, (unsigned)(a >> 32));
-  r.z = __builtin_bit_cast(float, (unsigned)(b & 0xffffffffu));
-  r.w = __builtin_bit_cast(float, (unsigned)(b >> 32));
-  return r;
-}
-// Bounded wait until *cnt >= target (one polling lane per workgroup, then barrier).  Returns
-// false on timeout: the caller proceeds (results are then wrong) and raises the error word —
-// a missed hand-off must never hang the GPU.
-#define KH_SPIN_LIMIT (1 << 14)  // ~16 ms per wait at ~1 us per poll: a broken hand-off costs seconds, never a hang
-// SLEEP: s_sleep argument between polls (64 cycles each): 8 (~0.2 us) for a few pollers per word,
-// 32 (~0.85 us) when ~64 workgroups share a word (one line serves ~88 requests/us).
-template <int SLEEP = 8>
-__device__ __forceinline__ void wait_counter(const int* cnt, int target, int* err_word) {
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(SLEEP);
-      if (++spins > KH_SPIN_LIMIT) {
-        __hip_atomic_store(err_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-// all threads: this workgroup's sc1 stores are out -> one arrival on `cnt`
-__device__ __forceinline__ void arrive_counter(int* cnt) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ---- wave64 cross-lane reductions without LDS ----------------------------------------------
 // hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-pipe instruction, ~50+ cycles each and six
 // of them in a dependent chain per reduction).  DPP quad/row permutes + the gfx950

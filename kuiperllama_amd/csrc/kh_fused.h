@@ -33,13 +33,10 @@ template <bool QUANT>
 __device__ __forceinline__ float* lds_red_ptr(f32x4* xs, int M) {
   return (float*)(xs + (QUANT ? 4 * ((M >> 4) + 1) : (M >> 2)));
 }
-// xs | red[KH_WAVES_MAX] | comb[2*KH_WAVES_MAX] (split-row partial sums) | argmax idx[KH_WAVES_MAX]
-// (cls) | scale slabs [waves][SP][2][64] (int8 scale prefetch, kh_gemv.h)
-static inline size_t fused_lds_bytes(bool quant, int M, int sp = 0, int wg = KH_WG_MAX) {
-  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 4 * KH_WAVES_MAX * sizeof(float) +
-         (size_t)(wg / KH_WAVE) * sp * 2 * KH_WAVE * sizeof(float);
+// xs | red[KH_WAVES_MAX] | comb[2*KH_WAVES_MAX] (split-row partial sums)
+static inline size_t fused_lds_bytes(bool quant, int M) {
+  return (quant ? kh_q8_lds_bytes(M) : (size_t)M * 4) + 3 * KH_WAVES_MAX * sizeof(float);
 }
-__device__ __forceinline__ float* lds_scale_ptr(float* red) { return red + 4 * KH_WAVES_MAX; }
 
 // Three-way select on VALUES.  Written as `w == 0 ? a : ...` directly on named variables, the
 // conditional operator yields an lvalue, clang selects between the variables' ADDRESSES, and the
@@ -48,22 +45,6 @@ template <class T>
 __device__ __forceinline__ T sel3(int w, T a, T b, T c) {
   return w == 0 ? a : (w == 1 ? b : c);
 }
-
-// Hand-off words of one layer for the merged [qkv | attention | wo] launch (kh_merged.h);
-// zeroed by k_sample at the end of every decode step.
-// Every counter sits in its own 128-byte line (KH_SYNC_STRIDE ints apart): agent-scope polls and
-// atomics are served at the memory side, where requests to one line serialise (~88 per us,
-// guide "dequeue" row) — 512 pollers on one word turned a 15 us stage into 50 us.  The
-// attention->wo counter is additionally replicated 8x (one per XCD, picked by workgroup id).
-#define KH_SYNC_STRIDE 32
-#define KH_SYNC_REPL 8
-struct KhSync {
-  int* cnt_qkv;     // [kv_heads][STRIDE] arrivals of qkv workgroup-iterations, per KV group
-  int* cnt_attn;    // [REPL][STRIDE]     arrivals of finished attention heads (replicated)
-  int* err;         // [1]        set when a bounded wait timed out
-  int expect_qkv;   // arrivals that complete one KV group's q, k and v rows
-  int expect_attn;  // = head_num
-};
 
 // ---------------------------------------------------------------------------------------------
 struct KhQkvArgs {
@@ -80,11 +61,9 @@ struct KhQkvArgs {
   float eps;
 };
 
-// MERGED: this stage shares its launch with its consumers: results leave with write-through
-// (sc1) stores and every workgroup-iteration arrives on its KV group's counter.
-template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED, int SP = 0>
-__device__ __forceinline__ void qkv_body(const KhQkvArgs& a, char* smem_raw, int vb, int vgrid,
-                                         const KhSync& sync) {
+template <bool QUANT, int U, int MAXV, int SPLIT>
+__global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // Every kernel argument used inside the lambdas is first copied into a scalar local: a
   // lambda that captures the argument STRUCT by reference keeps the whole struct addressable
   // and the compiler then parks it in scratch memory (seen as 168 B/lane of scratch traffic).
@@ -98,14 +77,12 @@ __device__ __forceinline__ void qkv_body(const KhQkvArgs& a, char* smem_raw, int
   const float* const cos_cache = a.cos_cache;
   const int dim = a.dim, kv_dim = a.kv_dim, rope_mode = a.rope_mode;
   const float eps = a.eps;
-  int* const cnt_qkv = sync.cnt_qkv;
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, dim);
   const int lane = threadIdx.x & 63;
   const int hs = a.head_size, half = hs >> 1;
   const int npq = dim >> 1, npk = kv_dim >> 1;
   const int total = npq + 2 * npk;
-  const int kv_mul = dim / kv_dim;
   const Gemv<QUANT, U> g(dim, a.gshift);
   Stager<true, QUANT, MAXV> st(a.x, a.att_norm, dim);
   const int pos = *a.d_pos;
@@ -170,80 +147,15 @@ __device__ __forceinline__ void qkv_body(const KhQkvArgs& a, char* smem_raw, int
       s0 = v0 * x.fcr - v1 * x.fci;
       s1 = v0 * x.fci + v1 * x.fcr;
     }
-    if (MERGED) {
-      st_sc1(dst + r0, s0);
-      st_sc1(dst + r1, s1);
-    } else {
-      dst[r0] = s0;
-      dst[r1] = s1;
-    }
+    dst[r0] = s0;
+    dst[r1] = s1;
   };
-  // MERGED: an aligned block of 4 pairs never straddles a (projection, KV group) boundary: per
-  // group there are kv_mul*hs/2 q pairs and hs/2 k (v) pairs, all multiples of 4 (checked at
-  // model build), so one arrival per workgroup-iteration on the group's counter
-  auto after = [&](int pf) __attribute__((always_inline)) {
-    if (!MERGED) return;
-    int* cnt = nullptr;
-    if (pf >= 0) {
-      int which, r0, r1, cidx;
-      decode(pf, which, r0, r1, cidx);
-      const int grp = which == 0 ? (r0 / hs) / kv_mul : r0 / hs;
-      cnt = cnt_qkv + grp * KH_SYNC_STRIDE;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores are out
-    __syncthreads();
-    if (cnt && threadIdx.x == 0)
-      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  gemv_pairs<QUANT, U, SPLIT, SP>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre, [&]() __attribute__((always_inline)) { st.issue(); },
-                                  [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi, vb, vgrid, after,
-                                  lds_scale_ptr(red));
-}
-template <bool QUANT, int U, int MAXV, int SPLIT, int SP = 0>
-__global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  qkv_body<QUANT, U, MAXV, SPLIT, false, SP>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x, KhSync{});
+  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre,
+                              [&]() __attribute__((always_inline)) { st.issue(); },
+                              [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int G, bool MERGED>
-__device__ __forceinline__ void attn_body(const KhAttnArgs& a, char* smem_raw, int b,
-                                          const KhSync& sync) {
-  const int pos = *a.d_pos;
-  // block -> (kv group g, head-in-group j, split s): blocks are placed on XCD b % 8, so with
-  // g = b % kv_heads the kv_mul heads that share K/V rows share an XCD's L2 (kv_heads % 8 == 0)
-  const int g = b % a.kv_heads;
-  const int j = (b / a.kv_heads) % a.kv_mul;
-  const int s = b / (a.kv_heads * a.kv_mul);
-  const int h = g * a.kv_mul + j;
-  const size_t head_off = (size_t)g * a.head_size;
-  if (MERGED) {
-    // splits that have nothing to do at this position leave before touching any counter
-    if (s >= attn_active_splits(pos, a.nsplit)) return;
-  }
-  // MERGED: q and cache row `pos` of this KV group are being produced by the qkv stage of the
-  // same launch.  The core first puts the OLDER K/V rows of its first batch in flight (they do
-  // not depend on this launch), then calls this (bounded) wait, then reads q and row `pos` with
-  // sc1 loads.
-  const int* const cq = sync.cnt_qkv + g * KH_SYNC_STRIDE;
-  const int eq = sync.expect_qkv;
-  int* const err = sync.err;
-  auto wait = [&]() __attribute__((always_inline)) {
-    if (MERGED) wait_counter<8>(cq, eq, err);
-  };
-  const bool wrote = attn_head_decode_fast<G, MERGED>(
-      a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
-      a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, (float*)smem_raw, h, s,
-      a.nsplit, attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), wait,
-      a.ws_stride);
-  if (MERGED && wrote) {  // uniform per workgroup: one arrival on every replica
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x < KH_SYNC_REPL)
-      __hip_atomic_fetch_add(sync.cnt_attn + threadIdx.x * KH_SYNC_STRIDE, 1, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 // head_size <= 32 (tiny test models): the generic LDS-score core of the op-level kernel
 __global__ __launch_bounds__(KH_WG_MAX) void k_attn_generic(const KhAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -266,25 +178,19 @@ struct KhGemvResArgs {
   float* x;          // [K] residual stream, updated in place
   int M, K, gshift;
 };
-// MERGED: the input vector is produced earlier in the same launch (attention output): the first
-// weight chunk and the residual are fetched FIRST, then the workgroup waits (bounded) for the
-// producers' counter and stages the vector with sc1 loads.
-template <bool QUANT, int U, int MAXV, int SPLIT, bool MERGED, int SP = 0>
-__device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem_raw, int vb,
-                                              int vgrid, const KhSync& sync) {
+template <bool QUANT, int U, int MAXV, int SPLIT>
+__global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // scalar locals for everything the lambdas touch (see qkv_body)
   const void* const w = a.w.w;
   const float* const scales = a.w.scales;
   float* const x = a.x;
   const int M = a.M;
-  const int* const cnt_attn = sync.cnt_attn;
-  int* const err = sync.err;
-  const int expect_attn = sync.expect_attn;
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, M);
   const int lane = threadIdx.x & 63;
   const Gemv<QUANT, U> g(M, a.gshift);
-  Stager<false, QUANT, MAXV, MERGED> st(a.vec, nullptr, M);
+  Stager<false, QUANT, MAXV> st(a.vec, nullptr, M);
   auto pair = [&](int p) __attribute__((always_inline)) { return g.rows(w, 2 * p, w, 2 * p + 1, scales, scales, M); };
   struct Aux {
     float x0, x1;
@@ -295,31 +201,21 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, char* smem
     x[2 * p] = r.x0 + s0;
     x[2 * p + 1] = r.x1 + s1;
   };
-  gemv_pairs<QUANT, U, SPLIT, SP>(
+  gemv_pairs<QUANT, U, SPLIT>(
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) {
 #if !KH_EXP_NOSTAGE
-        if (!MERGED) st.issue();
+        st.issue();
 #endif
       },
       [&]() __attribute__((always_inline)) {
 #if KH_EXP_NOSTAGE
         __syncthreads();  // ablation: x is never staged (wrong results; staging cost upper bound)
 #else
-        if (MERGED) {
-          wait_counter<32>(cnt_attn + (vb & (KH_SYNC_REPL - 1)) * KH_SYNC_STRIDE, expect_attn, err);
-          st.issue();
-        }
         st.finish(xs, 0.f, red);
 #endif
       },
-      epi, vb, vgrid, NoAfter(), lds_scale_ptr(red));
-}
-template <bool QUANT, int U, int MAXV, int SPLIT, int SP = 0>
-__global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  gemv_res_body<QUANT, U, MAXV, SPLIT, false, SP>(a, smem_raw, (int)blockIdx.x, (int)gridDim.x,
-                                                  KhSync{});
+      epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,7 +227,7 @@ struct KhFfn13Args {
   int dim, hidden, gshift;
   float eps;
 };
-template <bool QUANT, int U, int MAXV, int SP = 0>
+template <bool QUANT, int U, int MAXV>
 __global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -343,10 +239,9 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
   auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane == 0) a.h[r] = swiglu1(s0, s1);
   };
-  gemv_pairs<QUANT, U, 1, SP>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<QUANT, U, 1>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
-                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi,
-                       (int)blockIdx.x, (int)gridDim.x, NoAfter(), lds_scale_ptr(red));
+                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -360,7 +255,7 @@ struct KhClsArgs {
   int dim, vocab, gshift;
   float eps;
 };
-template <bool QUANT, int U, int MAXV, int SP = 0>
+template <bool QUANT, int U, int MAXV>
 __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -384,11 +279,10 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
       amax_merge(bv, bi, s1, r1);
     }
   };
-  gemv_pairs<QUANT, U, 1, SP>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
+  gemv_pairs<QUANT, U, 1>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
                           [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
-                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi,
-                       (int)blockIdx.x, (int)gridDim.x, NoAfter(), lds_scale_ptr(red));
+                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
   // stage-1 argmax: one partial per workgroup (ties -> lowest index)
   int* redi = (int*)(red + 3 * KH_WAVES_MAX);
   __syncthreads();
@@ -405,8 +299,8 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
     a.part_idx[blockIdx.x] = i;
   }
 }
-static inline size_t cls_lds_bytes(bool quant, int M, int sp = 0, int wg = KH_WG_MAX) {
-  return fused_lds_bytes(quant, M, sp, wg);
+static inline size_t cls_lds_bytes(bool quant, int M) {
+  return fused_lds_bytes(quant, M) + KH_WAVES_MAX * sizeof(int);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -425,11 +319,8 @@ struct KhSampleArgs {
   float* x;               // residual stream: receives the next token's embedding row
   int dim, vocab;
   int advance;            // 1: generate loop (feed next token, ++pos); 0: predict() only
-  int* sync_words;        // hand-off counters of the merged launches: re-armed every step
-  int n_sync;
 };
 __global__ __launch_bounds__(KH_WG) void k_sample(const KhSampleArgs a) {
-  for (int i = threadIdx.x; i < a.n_sync; i += KH_WG) a.sync_words[i] = 0;
   __shared__ float sv[KH_WAVES_PER_WG];
   __shared__ int si[KH_WAVES_PER_WG];
   __shared__ int s_next;

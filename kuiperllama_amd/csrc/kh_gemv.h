@@ -92,9 +92,7 @@ __device__ __forceinline__ void fma_chunk(const RegsF32<U>& r, const f32x4* xs, 
 // group c0/4 + l) and each lane picks its U scales with ds_bpermute (LDS crossbar, no memory
 // access) — instead of U more VMEM instructions per row, which doubled the vector-memory issue
 // count of the int8 kernels.  Other group sizes keep the direct per-load scale fetch.
-// WS = false: the scales of this wave's row pairs were prefetched into LDS (gemv_pairs, SP > 0);
-// only the weight loads are issued.
-template <int U, bool WS = true>
+template <int U>
 __device__ __forceinline__ void load_chunk(RegsQ8<U>& r, const RowsQ8& rows, int gshift, int c0,
                                            int M16, int lane) {
 #pragma unroll
@@ -104,7 +102,6 @@ __device__ __forceinline__ void load_chunk(RegsQ8<U>& r, const RowsQ8& rows, int
     r.q0[u] = ld_nt(rows.w0 + cidx);
     r.q1[u] = ld_nt(rows.w1 + cidx);
   }
-  if (!WS) return;
   if (KH_SCALE_BPERM && gshift == 6 && U <= 4) {
     const int ng = M16 >> 2;  // groups per row
     int gi = (c0 >> 2) + lane;
@@ -171,36 +168,6 @@ __device__ __forceinline__ void fma_chunk(const RegsQ8<U>& r, const f32x4* xs, i
   }
 }
 
-// Same arithmetic with the scales read from the wave's LDS copy (sl0 / sl1: this pair's two rows,
-// one float per 64-group of the wave's column range starting at chunk cb; 4 lanes share a group,
-// so the ds_read_b32 is a broadcast).  Bit-identical to fma_chunk: only the transport differs.
-template <int U>
-__device__ __forceinline__ void fma_chunk_sp(const RegsQ8<U>& r, const f32x4* xs, int c0, int M16,
-                                             int plane, int lane, float& a0, float& a1,
-                                             const float* sl0, const float* sl1, int cb) {
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int idx = c0 + u * KH_WAVE + lane;
-    if (idx < M16) {
-      const int gi = (idx - cb) >> 2;
-      const float g0 = sl0[gi], g1 = sl1[gi];
-      const f32x4 x0 = xs[idx], x1 = xs[plane + idx], x2 = xs[2 * plane + idx],
-                  x3 = xs[3 * plane + idx];
-      float t0 = 0.f, t1 = 0.f;
-      t0 = dot4_i8(r.q0[u].x, x0, t0);
-      t0 = dot4_i8(r.q0[u].y, x1, t0);
-      t0 = dot4_i8(r.q0[u].z, x2, t0);
-      t0 = dot4_i8(r.q0[u].w, x3, t0);
-      t1 = dot4_i8(r.q1[u].x, x0, t1);
-      t1 = dot4_i8(r.q1[u].y, x1, t1);
-      t1 = dot4_i8(r.q1[u].z, x2, t1);
-      t1 = dot4_i8(r.q1[u].w, x3, t1);
-      a0 = __builtin_fmaf(g0, t0, a0);
-      a1 = __builtin_fmaf(g1, t1, a1);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Uniform view over fp32 / int8 weight matrices so the kernels are written once.
 template <bool QUANT, int U>
@@ -218,7 +185,6 @@ struct Gemv<false, U> {
                 (const f32x4*)((const float*)w1_base + (size_t)r1 * M)};
   }
   // lim: end of this wave's column range in 16-byte units (== Mc unless the row is split)
-  template <bool WS = true>
   __device__ __forceinline__ void load(Regs& r, const Rows& rw, int c0, int lim, int lane) const {
     load_chunk<U>(r, rw, c0, lim, lane);
   }
@@ -226,12 +192,6 @@ struct Gemv<false, U> {
                                       float& a0, float& a1) const {
     fma_chunk<U>(r, xs, c0, lim, lane, a0, a1);
   }
-  __device__ __forceinline__ void fma_sp(const Regs& r, const f32x4* xs, int c0, int lim, int lane,
-                                         float& a0, float& a1, const float*, const float*,
-                                         int) const {
-    fma_chunk<U>(r, xs, c0, lim, lane, a0, a1);
-  }
-  __device__ __forceinline__ float scale_at(const float*, int) const { return 0.f; }
 };
 
 template <int U>
@@ -248,18 +208,12 @@ struct Gemv<true, U> {
                 (const i32x4*)((const int8_t*)w1_base + (size_t)r1 * M),
                 s0_base + (size_t)r0 * gpr, s1_base + (size_t)r1 * gpr};
   }
-  template <bool WS = true>
   __device__ __forceinline__ void load(Regs& r, const Rows& rw, int c0, int lim, int lane) const {
-    load_chunk<U, WS>(r, rw, gshift, c0, lim, lane);
+    load_chunk<U>(r, rw, gshift, c0, lim, lane);
   }
   __device__ __forceinline__ void fma(const Regs& r, const f32x4* xs, int c0, int lim, int lane,
                                       float& a0, float& a1) const {
     fma_chunk<U>(r, xs, c0, lim, Mc + 1, gshift, lane, a0, a1);
-  }
-  __device__ __forceinline__ void fma_sp(const Regs& r, const f32x4* xs, int c0, int lim, int lane,
-                                         float& a0, float& a1, const float* sl0, const float* sl1,
-                                         int cb) const {
-    fma_chunk_sp<U>(r, xs, c0, lim, Mc + 1, lane, a0, a1, sl0, sl1, cb);
   }
 };
 
@@ -278,32 +232,13 @@ struct Gemv<true, U> {
 // columns; partial sums are combined through LDS in fixed order (deterministic).  Used when a
 // matrix has too few rows to put >= ~4096 waves in flight (w2: 1024 pairs of 32 KiB rows), where
 // one wave per pair leaves 4 waves per CU and no load/compute overlap.  comb = LDS float[8].
-// vb / vgrid: the (virtual) workgroup index and count of this GEMV stage — blockIdx.x/gridDim.x
-// for a stand-alone kernel, a sub-range of the grid when several stages share one launch
-// (kh_merged.h).  AFTER(p_first): called by ALL threads once per iteration after the epilogues
-// (p_first = the iteration's first pair of this workgroup, -1 if the workgroup had none); the
-// merged launch uses it to publish "these rows are done" to the consumer stage.
-struct NoAfter {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-//
-// SP (int8, group size 64 only): scale prefetch.  The inner loop of the int8 kernels used to issue
-// one small scale load per 16-byte weight load - half of the vector-memory instructions of the
-// kernel for 6 % of its bytes.  With SP > 0 every wave fetches, right behind its first weight
-// chunk, the scales of ALL the row pairs it will process (<= SP iterations x 2 rows, one coalesced
-// dword per lane = one 64-group per lane of its column range, which must span <= 64 groups), parks
-// them in a wave-private LDS slab (slds: [waves][SP][2][64] floats) and the FMA loop reads them
-// from there.  The host picks SP >= iterations (launch shape) or 0.
-template <bool QUANT, int U, int SPLIT, int SP = 0, class PairFn, class PreFn, class IssueFn,
-          class FinishFn, class EpiFn, class AfterFn = NoAfter>
+template <bool QUANT, int U, int SPLIT, class PairFn, class PreFn, class IssueFn, class FinishFn,
+          class EpiFn>
 __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4* xs, int total,
                                            int lane, float* comb, PairFn&& PAIR, PreFn&& PRE,
-                                           IssueFn&& ISSUE, FinishFn&& FINISH, EpiFn&& EPI,
-                                           int vb = (int)blockIdx.x, int vgrid = (int)gridDim.x,
-                                           AfterFn&& AFTER = AfterFn(), float* slds = nullptr) {
+                                           IssueFn&& ISSUE, FinishFn&& FINISH, EpiFn&& EPI) {
+  const int vb = (int)blockIdx.x, vgrid = (int)gridDim.x;
   static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
-  static_assert(SP == 0 || QUANT, "scale prefetch is an int8 feature");
-  constexpr bool WS = SP == 0;  // weight loads carry their own scale loads
   const int PPW = kh_nwaves() / SPLIT;  // pairs per workgroup per iteration
   const int wave = threadIdx.x >> 6;
   const int part = wave & (SPLIT - 1);
@@ -322,27 +257,9 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
   // unconditional (an idle wave re-reads pair 0): a branch here would make the compiler merge
   // the vmcnt state of both paths and wait vmcnt(0) — i.e. for the weights — before using x.
   // The loads stay in flight across the staging barriers.
-  g.template load<WS>(regs, cur, cb, ce, lane);
-  float sreg[SP > 0 ? 2 * SP : 1];
-  float* const sl = SP > 0 ? slds + (size_t)wave * (2 * SP * KH_WAVE) : nullptr;
-  if constexpr (SP > 0) {
-    const int ng = (ce - cb + 3) >> 2;         // 64-groups in this wave's column range (<= 64)
-    const int k = (cb >> 2) + (lane < ng ? lane : 0);
-#pragma unroll
-    for (int it = 0; it < SP; ++it) {
-      const int pi = gp + it * np;
-      const auto rw = PAIR(pi < total ? pi : p0);
-      sreg[2 * it] = rw.sc0[k];
-      sreg[2 * it + 1] = rw.sc1[k];
-    }
-  }
+  g.load(regs, cur, cb, ce, lane);
   auto aux = PRE(p0);
   FINISH();
-  if constexpr (SP > 0) {
-#pragma unroll
-    for (int j = 0; j < 2 * SP; ++j) sl[j * KH_WAVE + lane] = sreg[j];
-    __builtin_amdgcn_wave_barrier();  // wave-private slab: LDS ops of one wave execute in order
-  }
   const int iters = (total + np - 1) / np;  // uniform trip count: the SPLIT path has barriers
   for (int it = 0; it < iters; ++it) {
     const int p = gp + it * np;
@@ -350,21 +267,17 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
     float a0 = 0.f, a1 = 0.f;
     if (valid) {
       for (int c0 = cb;;) {
-        if constexpr (SP > 0)
-          g.fma_sp(regs, xs, c0, ce, lane, a0, a1, sl + (2 * it) * KH_WAVE,
-                   sl + (2 * it + 1) * KH_WAVE, cb);
-        else
-          g.fma(regs, xs, c0, ce, lane, a0, a1);
+        g.fma(regs, xs, c0, ce, lane, a0, a1);
         c0 += step;
         if (c0 >= ce) break;
-        g.template load<WS>(regs, cur, c0, ce, lane);
+        g.load(regs, cur, c0, ce, lane);
       }
     }
     const int pn = p + np;
     auto aux_next = aux;
     if (pn < total) {  // next pair's first chunk is in flight during the reduction + epilogue
       cur = PAIR(pn);
-      g.template load<WS>(regs, cur, cb, ce, lane);
+      g.load(regs, cur, cb, ce, lane);
       aux_next = PRE(pn);
     }
     float s0 = wave_sum(a0), s1 = wave_sum(a1);
@@ -387,10 +300,6 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
         EPI(p, s0, s1, aux);
       }
       __syncthreads();
-    }
-    {
-      const int pf = vb * PPW + it * np;  // first pair of this workgroup in this iteration
-      AFTER(pf < total ? pf : -1);
     }
     aux = aux_next;
   }
@@ -442,10 +351,7 @@ __device__ __forceinline__ void stage_vec(const float* __restrict__ x,
 // waitcnt merge degrades to vmcnt(0) = "wait for the weights too"):
 //   MAXV = 4  vectors up to 4096 floats (dim of every BASELINE config)
 //   MAXV = 0  any length: single-phase stage_vec after the first weight loads were issued
-// SC1: the vector was written earlier in the SAME launch by other workgroups with write-through
-// (sc1) stores; it is then read with agent-scope relaxed atomic loads (sc1: bypass the
-// non-coherent L1 / remote-L2 copies) instead of plain loads (kh_merged.h).
-template <bool NORM, bool LAYOUT_Q8, int MAXV, bool SC1 = false>
+template <bool NORM, bool LAYOUT_Q8, int MAXV>
 struct Stager {
   f32x4 xv[MAXV > 0 ? MAXV : 1];
   f32x4 wv[(NORM && MAXV > 0) ? MAXV : 1];
@@ -463,7 +369,7 @@ struct Stager {
       for (int v = 0; v < MAXV; ++v) {
         const int i = threadIdx.x + v * kh_wg();
         const int ci = i < M4 ? i : 0;
-        xv[v] = SC1 ? ld4_sc1(x4 + ci) : x4[ci];
+        xv[v] = x4[ci];
         if (NORM) wv[v] = w4[ci];
       }
     }

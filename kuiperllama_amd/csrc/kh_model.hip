@@ -20,7 +20,6 @@
 #include <thread>
 #include <vector>
 
-#include "kh_merged.h"
 #include "kh_prefill.h"
 
 namespace {
@@ -54,9 +53,6 @@ struct kh_model {
   int32_t* part_idx = nullptr;
   int nparts = 0;
   float load_ms = 0.f;      // host image -> HBM upload time (kh_model_get_load_ms)
-  int* sync_words = nullptr;  // hand-off counters of the merged launches + 1 error word
-  int n_sync = 0;
-  int merge_combo = -1;       // kh_merged.h combination id, -1 = stand-alone kernels
   void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
   int attn_ns = 1;
   int attn_ns_g = 0;        // GQA long-context path: splits per KV group (0 = path off)
@@ -76,7 +72,6 @@ struct kh_model {
   // launch geometry
   struct Shape {
     int u = 2, split = 1, grid = 1, wg = KH_WG;
-    int sp = 0;  // int8 scale-prefetch depth (kh_gemv.h): 0 = scales loaded beside the weights
   };
   Shape sh_qkv, sh_wo, sh_ffn, sh_w2, sh_cls;
   // graph
@@ -164,21 +159,6 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
   return sh;
 }
 
-// int8 scale prefetch (kh_gemv.h, SP): usable when the group size is the exporter's 64, a wave's
-// column range spans at most 64 groups and the shape gives every wave at most `spn` row pairs.
-// KH_Q8_SP=0 switches it off (A/B measurements).
-int pick_sp(bool quant, int gshift, const kh_model::Shape& sh, int pairs, int M, int spn) {
-  if (!quant || gshift != 6) return 0;
-  if (const char* e = getenv("KH_Q8_SP"))
-    if (e[0] == '0') return 0;
-  const int ppw = (sh.wg / KH_WAVE) / sh.split;
-  const int iters = (pairs + sh.grid * ppw - 1) / (sh.grid * ppw);
-  const int Mc = M / 16;
-  const int Q = (((Mc + sh.split - 1) / sh.split) + 3) & ~3;
-  if (Q > 4 * KH_WAVE) return 0;
-  return iters <= spn ? spn : 0;
-}
-
 int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
   int s = 0;
@@ -190,72 +170,54 @@ int ilog2_exact(int v) {
 // Template dispatch.  U: 16-byte loads per row in flight per lane; MV: in-register staging depth
 // (kh_stage_maxv of the input length); SP: waves sharing one row pair.
 // The workgroup size comes from a variable `kh_launch_wg` in scope at the dispatch site.
-// SPN: the scale-prefetch depth this kernel class is instantiated with (kh_gemv.h, int8 only);
-// used when the launch shape asks for it (`kh_launch_sp` in scope), else the SP = 0 kernel.
-#define KH_L3(KERNEL, SPN, Q, UU, MV, GRID, LDS, STREAM, ARGS)                                    \
-  do {                                                                                            \
-    if ((Q) && kh_launch_sp == (SPN))                                                             \
-      hipLaunchKernelGGL((KERNEL<Q, UU, MV, ((Q) ? (SPN) : 0)>), dim3(GRID), dim3(kh_launch_wg),  \
-                         LDS, STREAM, ARGS);                                                      \
-    else                                                                                          \
-      hipLaunchKernelGGL((KERNEL<Q, UU, MV, 0>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM,     \
-                         ARGS);                                                                   \
-  } while (0)
-#define KH_L4(KERNEL, SPN, Q, UU, MV, SP, GRID, LDS, STREAM, ARGS)                                \
-  do {                                                                                            \
-    if ((Q) && kh_launch_sp == (SPN))                                                             \
-      hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP, ((Q) ? (SPN) : 0)>), dim3(GRID),                  \
-                         dim3(kh_launch_wg), LDS, STREAM, ARGS);                                  \
-    else                                                                                          \
-      hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP, 0>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, \
-                         ARGS);                                                                   \
-  } while (0)
-#define KH_SEL_MV3(KERNEL, SPN, Q, UU, MV, ...)             \
+#define KH_L3(KERNEL, Q, UU, MV, GRID, LDS, STREAM, ARGS) \
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
+#define KH_L4(KERNEL, Q, UU, MV, SP, GRID, LDS, STREAM, ARGS) \
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
+#define KH_SEL_MV3(KERNEL, Q, UU, MV, ...)                  \
   do {                                                      \
     if ((MV) == 4)                                          \
-      KH_L3(KERNEL, SPN, Q, UU, 4, __VA_ARGS__);            \
+      KH_L3(KERNEL, Q, UU, 4, __VA_ARGS__);                 \
     else                                                    \
-      KH_L3(KERNEL, SPN, Q, UU, 0, __VA_ARGS__);            \
+      KH_L3(KERNEL, Q, UU, 0, __VA_ARGS__);                 \
   } while (0)
-#define KH_SEL_SP4(KERNEL, SPN, Q, UU, MV, SP, ...)         \
+#define KH_SEL_SP4(KERNEL, Q, UU, MV, SP, ...)              \
   do {                                                      \
     if ((SP) == 4)                                          \
-      KH_L4(KERNEL, SPN, Q, UU, MV, 4, __VA_ARGS__);        \
+      KH_L4(KERNEL, Q, UU, MV, 4, __VA_ARGS__);             \
     else if ((SP) == 2)                                     \
-      KH_L4(KERNEL, SPN, Q, UU, MV, 2, __VA_ARGS__);        \
+      KH_L4(KERNEL, Q, UU, MV, 2, __VA_ARGS__);             \
     else                                                    \
-      KH_L4(KERNEL, SPN, Q, UU, MV, 1, __VA_ARGS__);        \
+      KH_L4(KERNEL, Q, UU, MV, 1, __VA_ARGS__);             \
   } while (0)
-#define KH_SEL_MV4(KERNEL, SPN, Q, UU, MV, SP, ...)         \
+#define KH_SEL_MV4(KERNEL, Q, UU, MV, SP, ...)              \
   do {                                                      \
     if ((MV) == 4)                                          \
-      KH_SEL_SP4(KERNEL, SPN, Q, UU, 4, SP, __VA_ARGS__);   \
+      KH_SEL_SP4(KERNEL, Q, UU, 4, SP, __VA_ARGS__);        \
     else                                                    \
-      KH_SEL_SP4(KERNEL, SPN, Q, UU, 0, SP, __VA_ARGS__);   \
+      KH_SEL_SP4(KERNEL, Q, UU, 0, SP, __VA_ARGS__);        \
   } while (0)
-#define KH_SEL_U(SEL, KERNEL, SPN, QUANT, U, ...)           \
+#define KH_SEL_U(SEL, KERNEL, QUANT, U, ...)                \
   do {                                                      \
     if (QUANT) {                                            \
       if ((U) >= 4)                                         \
-        SEL(KERNEL, SPN, true, 4, __VA_ARGS__);             \
+        SEL(KERNEL, true, 4, __VA_ARGS__);                  \
       else                                                  \
-        SEL(KERNEL, SPN, true, 2, __VA_ARGS__);             \
+        SEL(KERNEL, true, 2, __VA_ARGS__);                  \
     } else {                                                \
       if ((U) >= 8)                                         \
-        SEL(KERNEL, SPN, false, 8, __VA_ARGS__);            \
+        SEL(KERNEL, false, 8, __VA_ARGS__);                 \
       else if ((U) >= 4)                                    \
-        SEL(KERNEL, SPN, false, 4, __VA_ARGS__);            \
+        SEL(KERNEL, false, 4, __VA_ARGS__);                 \
       else                                                  \
-        SEL(KERNEL, SPN, false, 2, __VA_ARGS__);            \
+        SEL(KERNEL, false, 2, __VA_ARGS__);                 \
     }                                                       \
   } while (0)
 // kernels without / with the SPLIT parameter
-#define KH_DISPATCH3(KERNEL, SPN, QUANT, U, MV, GRID, LDS, STREAM, ARGS) \
-  KH_SEL_U(KH_SEL_MV3, KERNEL, SPN, QUANT, U, MV, GRID, LDS, STREAM, ARGS)
-#define KH_DISPATCH4(KERNEL, SPN, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
-  KH_SEL_U(KH_SEL_MV4, KERNEL, SPN, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
-#define KH_SPN_LAYER 4  // per-layer GEMVs: up to 4 row pairs per wave
-#define KH_SPN_CLS 8    // classifier: up to 8
+#define KH_DISPATCH3(KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV3, KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS)
+#define KH_DISPATCH4(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV4, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
 
 KhQkvArgs fill_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -284,9 +246,9 @@ void launch_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const KhQkvArgs a = fill_qkv(m, l);
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_qkv.wg, kh_launch_sp = m->sh_qkv.sp;
-  KH_DISPATCH4(k_qkv, KH_SPN_LAYER, qn, m->sh_qkv.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_qkv.split,
-               m->sh_qkv.grid, fused_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
+  const int kh_launch_wg = m->sh_qkv.wg;
+  KH_DISPATCH4(k_qkv, qn, m->sh_qkv.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_qkv.split, m->sh_qkv.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 KhAttnArgs fill_attn(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -339,9 +301,9 @@ void launch_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
   const KhGemvResArgs a = fill_wo(m, l);
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_wo.wg, kh_launch_sp = m->sh_wo.sp;
-  KH_DISPATCH4(k_gemv_res, KH_SPN_LAYER, qn, m->sh_wo.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_wo.split,
-               m->sh_wo.grid, fused_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
+  const int kh_launch_wg = m->sh_wo.wg;
+  KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_wo.split, m->sh_wo.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 void launch_ffn13(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -357,9 +319,9 @@ void launch_ffn13(kh_model* m, int l) {
   a.gshift = m->gshift;
   a.eps = c.rms_eps;
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_ffn.wg, kh_launch_sp = m->sh_ffn.sp;
-  KH_DISPATCH3(k_ffn13, KH_SPN_LAYER, qn, m->sh_ffn.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_ffn.grid,
-               fused_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
+  const int kh_launch_wg = m->sh_ffn.wg;
+  KH_DISPATCH3(k_ffn13, qn, m->sh_ffn.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_ffn.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
 }
 void launch_w2(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -371,9 +333,9 @@ void launch_w2(kh_model* m, int l) {
   a.K = c.dim;
   a.gshift = m->gshift;
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_w2.wg, kh_launch_sp = m->sh_w2.sp;
-  KH_DISPATCH4(k_gemv_res, KH_SPN_LAYER, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split,
-               m->sh_w2.grid, fused_lds_bytes(qn, c.hidden_dim, kh_launch_sp, kh_launch_wg), m->stream, a);
+  const int kh_launch_wg = m->sh_w2.wg;
+  KH_DISPATCH4(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split, m->sh_w2.grid,
+               fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
 }
 void launch_cls(kh_model* m) {
   const kh_config& c = m->cfg;
@@ -390,9 +352,9 @@ void launch_cls(kh_model* m) {
   a.eps = c.rms_eps;
   // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
   const bool qn = c.is_quant;
-  const int kh_launch_wg = m->sh_cls.wg, kh_launch_sp = m->sh_cls.sp;
-  KH_DISPATCH3(k_cls, KH_SPN_CLS, qn, m->sh_cls.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_cls.grid,
-               cls_lds_bytes(qn, c.dim, kh_launch_sp, kh_launch_wg), m->stream, a);
+  const int kh_launch_wg = m->sh_cls.wg;
+  KH_DISPATCH3(k_cls, qn, m->sh_cls.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_cls.grid, cls_lds_bytes(qn, c.dim),
+               m->stream, a);
 }
 void launch_sample(kh_model* m, int advance, int n_forced) {
   const kh_config& c = m->cfg;
@@ -412,53 +374,23 @@ void launch_sample(kh_model* m, int advance, int n_forced) {
   a.dim = c.dim;
   a.vocab = c.vocab_size;
   a.advance = advance;
-  a.sync_words = m->sync_words;
-  a.n_sync = m->n_sync;  // re-arms every hand-off counter (not the error word)
   hipLaunchKernelGGL(k_sample, dim3(1), dim3(KH_WG), 0, m->stream, a);
 }
 
-// [qkv | attention | wo] of layer l as ONE launch with in-launch hand-offs (kh_merged.h)
-void launch_layer_a_merged(kh_model* m, int l) {
-  const kh_config& c = m->cfg;
-  KhLayerAArgs a;
-  a.qkv = fill_qkv(m, l);
-  a.attn = fill_attn(m, l);
-  a.wo = fill_wo(m, l);
-  int* base = m->sync_words + (size_t)l * (c.kv_head_num + KH_SYNC_REPL) * KH_SYNC_STRIDE;
-  a.sync.cnt_qkv = base;
-  a.sync.cnt_attn = base + (size_t)c.kv_head_num * KH_SYNC_STRIDE;
-  a.sync.err = m->sync_words + m->n_sync;
-  const int ppw = KH_WAVES_PER_WG / m->sh_qkv.split;
-  a.sync.expect_qkv = (c.kv_mul * c.head_size / 2 + c.head_size) / ppw;
-  a.sync.expect_attn = c.head_num;
-  a.n_qkv = m->sh_qkv.grid;
-  a.n_attn = c.head_num * m->attn_ns;
-  a.n_wo = m->sh_wo.grid;
-  size_t lds = fused_lds_bytes(c.is_quant, c.dim);
-  if (attn_fast_lds_bytes(c.head_size) > lds) lds = attn_fast_lds_bytes(c.head_size);
-  launch_layer_a(m->merge_combo, a.n_qkv + a.n_attn + a.n_wo, lds, m->stream, a);
-}
-
-// one fused decode step = 5L + 2 launches (3L + 2 with the merged [qkv|attn|wo] launch).
-// ev (optional) receives an event after each launch; event timing always uses the 5-kernel form.
+// one fused decode step = 5L + 2 launches.  ev (optional) receives an event after each launch.
 void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev) {
   int e = 0;
   auto mark = [&]() {
     if (ev) (void)hipEventRecord(ev[e++], m->stream);
   };
   mark();
-  const bool merged = m->merge_combo >= 0 && !ev;
   for (int l = 0; l < m->cfg.layer_num; ++l) {
-    if (merged) {
-      launch_layer_a_merged(m, l);
-    } else {
-      launch_qkv(m, l);
-      mark();
-      launch_attn(m, l);
-      mark();
-      launch_wo(m, l);
-      mark();
-    }
+    launch_qkv(m, l);
+    mark();
+    launch_attn(m, l);
+    mark();
+    launch_wo(m, l);
+    mark();
     launch_ffn13(m, l);
     mark();
     launch_w2(m, l);
@@ -568,18 +500,6 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
   if (ms_out)
     *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return e;
-}
-
-// after a synchronised run: did any bounded in-launch wait time out?  (re-arms the word)
-int check_sync_err(kh_model* m) {
-  if (m->merge_combo < 0) return KH_OK;
-  int h = 0;
-  KH_CHECK_HIP(hipMemcpyAsync(&h, m->sync_words + m->n_sync, sizeof(int), hipMemcpyDeviceToHost,
-                              m->stream));
-  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
-  if (h == 0) return KH_OK;
-  KH_CHECK_HIP(hipMemsetAsync(m->sync_words + m->n_sync, 0, sizeof(int), m->stream));
-  return KH_ERR_SYNC;
 }
 
 template <typename T>
@@ -808,39 +728,15 @@ int finish_create(kh_model* m) {
   m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS",
                          c.is_quant ? KH_WG : KH_WG_MAX, KH_WG_MAX);
   m->nparts = m->sh_cls.grid;
-  m->sh_qkv.sp = pick_sp(c.is_quant, m->gshift, m->sh_qkv, (c.dim + 2 * c.kv_dim) / 2, c.dim, KH_SPN_LAYER);
-  m->sh_wo.sp = pick_sp(c.is_quant, m->gshift, m->sh_wo, c.dim / 2, c.dim, KH_SPN_LAYER);
-  m->sh_ffn.sp = pick_sp(c.is_quant, m->gshift, m->sh_ffn, c.hidden_dim, c.dim, KH_SPN_LAYER);
-  m->sh_w2.sp = pick_sp(c.is_quant, m->gshift, m->sh_w2, c.dim / 2, c.hidden_dim, KH_SPN_LAYER);
-  m->sh_cls.sp = pick_sp(c.is_quant, m->gshift, m->sh_cls, (c.vocab_size + 1) / 2, c.dim, KH_SPN_CLS);
-  m->n_sync = c.layer_num * (c.kv_head_num + KH_SYNC_REPL) * KH_SYNC_STRIDE;
-  KH_CHECK_HIP(hipMalloc((void**)&m->sync_words, sizeof(int) * (size_t)(m->n_sync + 1)));
-  KH_CHECK_HIP(hipMemsetAsync(m->sync_words, 0, sizeof(int) * (size_t)(m->n_sync + 1), m->stream));
-  m->merge_combo = -1;
-  {
-    // merged [qkv|attn|wo] launch: only for instantiated shapes, dim within the in-register
-    // staging depth, pair blocks that do not straddle KV groups; opt-in (KH_FLAG_MERGE / KH_MERGE=1)
-    const char* env = getenv("KH_MERGE");
-    const bool off = !((m->opts.flags & KH_FLAG_MERGE) || (env && env[0] == '1'));
-    const int ppw = KH_WAVES_PER_WG / m->sh_qkv.split;
-    const bool aligned = ((c.kv_mul * c.head_size / 2) % 4 == 0) && ((c.head_size / 2) % 4 == 0) &&
-                         ((c.kv_mul * c.head_size / 2 + c.head_size) % ppw == 0);
-    if (!off && c.head_size > 32 && kh_stage_maxv(c.dim) == 4 && aligned &&
-        m->sh_qkv.wg == KH_WG && m->sh_wo.wg == KH_WG)
-      m->merge_combo = merged_combo_id(c.is_quant, m->sh_qkv.u, m->sh_qkv.split,
-                                       attn_group_lanes(c), m->sh_wo.u, m->sh_wo.split);
-    if (m->merge_combo >= 0) m->sh_qkv.sp = m->sh_wo.sp = 0;  // the merged launch has no SP form
-  }
   m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
-  // attention: 8 waves per (head, split) shorten each lane's timestep loop; the merged launch
-  // shares its workgroup size with qkv/wo
-  m->attn_wg = m->merge_combo >= 0 ? KH_WG : KH_WG_MAX;
+  // attention: 8 waves per (head, split) shorten each lane's timestep loop
+  m->attn_wg = KH_WG_MAX;
   if (const char* e = getenv("KH_ATTN_WG"))
-    if (m->merge_combo < 0 && (atoi(e) == 256 || atoi(e) == 512)) m->attn_wg = atoi(e);
+    if (atoi(e) == 256 || atoi(e) == 512) m->attn_wg = atoi(e);
   // GQA long-context path (kh_attn.h): one workgroup per (kv group, split) from pos + 1 >=
   // t_long on; KH_ATTN_TLONG overrides the threshold (0 = never)
   m->attn_ws_stride = m->attn_ns;
-  if (c.kv_mul > 1 && c.head_size > 32 && m->merge_combo < 0 &&
+  if (c.kv_mul > 1 && c.head_size > 32 &&
       attn_group_supported(c.head_size, c.kv_mul, m->attn_wg)) {
     // default policy: models with few KV heads (Qwen2.5-0.5B: 2) cannot fill the chip with
     // (group, split) workgroups and stay per-head; an explicit KH_ATTN_TLONG overrides
@@ -882,18 +778,12 @@ int finish_create(kh_model* m) {
     KH_CHECK_HIP(hipMemcpy(m->cos_cache, hc_.data(), n * sizeof(float), hipMemcpyHostToDevice));
   }
   // big activation vectors (hidden > 16 K floats) need the >64 KiB dynamic-LDS opt-in
-  size_t lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim, m->sh_w2.sp, m->sh_w2.wg);
-  if (lds_need > 160 * 1024 && m->sh_w2.sp) {
-    m->sh_w2.sp = 0;
-    lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim, 0, m->sh_w2.wg);
-  }
+  const size_t lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim);
   if (lds_need > 160 * 1024) return KH_ERR_UNSUPPORTED;
   if (lds_need > 64 * 1024) {
     const int v = (int)lds_need;
 #define KH_ATTR(Q, UU, SP)                                                                     \
-  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP, 0>,                          \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, v);                    \
-  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP, ((Q) ? KH_SPN_LAYER : 0)>,   \
+  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP>,                             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, v)
     KH_ATTR(false, 8, 1); KH_ATTR(false, 8, 2); KH_ATTR(false, 8, 4);
     KH_ATTR(false, 4, 1); KH_ATTR(false, 4, 2); KH_ATTR(false, 4, 4);
@@ -955,7 +845,7 @@ extern "C" void kh_model_destroy(kh_model* m) {
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
                   m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
                   m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
-                  m->d_forced, m->d_words, m->attn_ws, m->sync_words};
+                  m->d_forced, m->d_words, m->attn_ws};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (m->owns_arena && m->arena) (void)hipFree(m->arena);
@@ -1056,8 +946,7 @@ extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* 
 extern "C" int kh_model_get_config(const kh_model* m, kh_config* out) {
   if (!m || !out) return KH_ERR_INVALID_ARG;
   *out = m->cfg;
-  out->merged_launch = m->merge_combo >= 0;
-  out->launches_per_token = (m->merge_combo >= 0 ? 3 : 5) * m->cfg.layer_num + 2;
+  out->launches_per_token = 5 * m->cfg.layer_num + 2;
   return KH_OK;
 }
 extern "C" float kh_model_get_load_ms(const kh_model* m) { return m ? m->load_ms : -1.f; }
@@ -1111,7 +1000,7 @@ extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t
   KH_CHECK_HIP(hipMemcpyAsync(&next, m->d_next, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   *h_next = is_prompt ? -1 : next;  // post_processing (llama3.cpp:733-745)
-  return check_sync_err(m);
+  return KH_OK;
 }
 
 // ---- prompt prefill (kh_prefill.h) ---------------------------------------------------------------
@@ -1126,7 +1015,7 @@ int prefill_batch(const kh_model* m) {
 // decode path uses at these sizes (in-register, MAXV = 4) and for the fast attention core.
 bool prefill_supported(const kh_model* m) {
   const kh_config& c = m->cfg;
-  if (c.head_size <= 32 || m->merge_combo >= 0) return false;
+  if (c.head_size <= 32) return false;
   if (kh_stage_maxv(c.dim, m->sh_qkv.wg) != 4 || kh_stage_maxv(c.dim, m->sh_ffn.wg) != 4) return false;
   if (m->sh_qkv.split > 2 || m->sh_ffn.split != 1) return false;
   if (pf_lds_bytes(c.is_quant, c.dim, 4) > 160 * 1024) return false;
@@ -1359,7 +1248,7 @@ extern "C" int kh_model_time_prefill(kh_model* m, const int32_t* h_tokens, int32
   KH_CHECK_HIP(hipEventSynchronize(m->ev1));
   KH_CHECK_HIP(hipEventElapsedTime(h_ms, m->ev0, m->ev1));
   if ((rc = kh_launch_status()) != KH_OK) return rc;
-  return check_sync_err(m);
+  return KH_OK;
 }
 
 extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
@@ -1505,7 +1394,7 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   }
   if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
   *n_words = n_out;
-  return check_sync_err(m);
+  return KH_OK;
 }
 
 extern "C" int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos, int32_t reps,
@@ -1556,7 +1445,7 @@ extern "C" int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos,
   float ms = 0.f;
   KH_CHECK_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));
   *h_avg_us = ms * 1e3f / (float)(reps * n_inner);
-  return check_sync_err(m);
+  return KH_OK;
 }
 
 extern "C" int kh_model_time_step(kh_model* m, int32_t pos, int32_t reps, float* h_us) {
@@ -1574,7 +1463,7 @@ extern "C" int kh_model_time_step(kh_model* m, int32_t pos, int32_t reps, float*
     KH_CHECK_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));
     h_us[r] = ms * 1e3f;
   }
-  return check_sync_err(m);
+  return KH_OK;
 }
 
 static const char* const kKClassNames[KH_NUM_KCLASS] = {"qkv", "attn", "wo", "ffn13", "w2", "cls",

@@ -16,8 +16,6 @@ from ._ffi import KH_EXEC_FUSED, KH_EXEC_GRAPH, KH_EXEC_UNFUSED  # noqa: F401
 EXEC = {"graph": KH_EXEC_GRAPH, "fused": KH_EXEC_FUSED, "unfused": KH_EXEC_UNFUSED}
 
 
-KH_FLAG_MERGE = 2  # experimental merged [qkv|attention|wo] launch (off by default)
-
 
 def _opts(spec: binfmt.ModelSpec, max_seq_len: int, device: int, flags: int = 0) -> _ffi.ModelOpts:
     return _ffi.ModelOpts(spec.family, int(spec.quant), spec.rope_mode, spec.rope_theta,
