@@ -224,6 +224,15 @@ int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prom
  * geometries outside the mirrored kernels (head_size <= 32, dim > 4096). */
 int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
 
+/* The same contract with the contractions as fp32-MFMA GEMMs (csrc/kh_gemm.h): up to 128 prompt
+ * tokens share one pass over the weights (v_mfma_f32_16x16x4_f32, exact fp32 arithmetic, tokens on
+ * the MFMA N dimension; int8 weights dequantised per element in registers).  The K/V rows agree
+ * with the token-by-token path to fp32 round-off (different summation order), not bit for bit.
+ * kh_model_generate* use it for prompts with >= 16 fed-only tokens (env KH_PREFILL = 0 | gemv |
+ * gemm overrides).  KH_ERR_UNSUPPORTED: head_size <= 32, dim/hidden not a multiple of 16 (fp32) /
+ * 64 (int8), int8 group size != 64. */
+int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
+
 /* Duration (ms, HIP events on the model stream) of the prompt phase alone for n fed-only tokens:
  * KH_PREFILL_TOKEN = the reference's prompt phase, one forward pass per token (demo/main.cpp:20-22)
  * replayed from the decode hipGraph; KH_PREFILL_GEMV = kh_model_prefill's bit-identical B-token

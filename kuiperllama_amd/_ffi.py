@@ -24,7 +24,7 @@ EXPORTS = [
     "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
     "kh_spm_create_from_file", "kh_spm_create_from_memory", "kh_spm_destroy", "kh_spm_vocab_size",
     "kh_spm_bos_id", "kh_spm_eos_id", "kh_spm_unk_id", "kh_spm_encode", "kh_spm_decode",
-    "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
+    "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
 ]
 
 KH_EXEC_GRAPH, KH_EXEC_FUSED, KH_EXEC_UNFUSED = 0, 1, 2
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
     L.kh_spm_decode.argtypes = [_vp, C.POINTER(_i32), _i32, C.c_char_p, C.c_int64,
                                 C.POINTER(C.c_int64)]
     L.kh_model_prefill.argtypes = [_vp, C.POINTER(_i32), _i32, _i32]
+    L.kh_model_prefill_gemm.argtypes = [_vp, C.POINTER(_i32), _i32, _i32]
     L.kh_model_time_prefill.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_f32)]
     L.kh_model_profile_kernel.argtypes = [_vp, _i32, _i32, _i32, C.POINTER(_f32)]
     L.kh_model_profile_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32), C.POINTER(_i32)]

@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "kh_gemm.h"
 #include "kh_prefill.h"
 
 namespace {
@@ -66,6 +67,10 @@ struct kh_model {
   float *pf_x = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
   void* pf_ws = nullptr;        // KH_PF_BMAX attention split workspaces
   size_t pf_ws_tok_bytes = 0;
+  // GEMM prefill (kh_gemm.h): slabs of KH_PG_TMAX token rows
+  float *pg_x = nullptr, *pg_xn = nullptr, *pg_q = nullptr, *pg_att = nullptr, *pg_h = nullptr;
+  void* pg_ws = nullptr;        // KH_PG_TMAX attention split workspaces
+  size_t pg_ws_tok_bytes = 0;
   int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check)
   int pin_cap = 0;
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
@@ -543,6 +548,7 @@ int ensure_seq_cap(kh_model* m, int n) {
 }
 
 #define KH_GRAPH_STEPS 8
+#define KH_PG_MIN_TOKENS 16  // prompts with fewer fed-only tokens stay on the bit-identical path
 int capture_steps(kh_model* m, int n_forced, int steps, hipGraph_t* g, hipGraphExec_t* ge) {
   KH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
   for (int i = 0; i < steps; ++i) launch_step_fused(m, /*advance=*/1, n_forced, nullptr);
@@ -837,7 +843,9 @@ extern "C" void kh_model_destroy(kh_model* m) {
   if (m->graphN) (void)hipGraphDestroy(m->graphN);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
-  for (void* q : {(void*)m->pf_x, (void*)m->pf_q, (void*)m->pf_att, (void*)m->pf_h, m->pf_ws})
+  for (void* q : {(void*)m->pf_x, (void*)m->pf_q, (void*)m->pf_att, (void*)m->pf_h, m->pf_ws,
+                  (void*)m->pg_x, (void*)m->pg_xn, (void*)m->pg_q, (void*)m->pg_att, (void*)m->pg_h,
+                  m->pg_ws})
     if (q) (void)hipFree(q);
   for (auto e : m->ev_chunk)
     if (e) (void)hipEventDestroy(e);
@@ -1020,8 +1028,6 @@ bool prefill_supported(const kh_model* m) {
   if (m->sh_qkv.split > 2 || m->sh_ffn.split != 1) return false;
   if (pf_lds_bytes(c.is_quant, c.dim, 4) > 160 * 1024) return false;
   if (pf_lds_bytes(c.is_quant, c.hidden_dim, 2) > 160 * 1024) return false;
-  if (const char* e = getenv("KH_PREFILL"))
-    if (e[0] == '0') return false;
   return true;
 }
 int ensure_prefill_buffers(kh_model* m) {
@@ -1185,6 +1191,141 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
 }
 }  // namespace
 
+// ---- GEMM prefill (kh_gemm.h) ------------------------------------------------------------------
+namespace {
+bool pg_supported(const kh_model* m) {
+  const kh_config& c = m->cfg;
+  if (c.head_size <= 32) return false;  // attention: the fast multi-token decode kernel
+  const int kq = c.is_quant ? 64 : 16;  // K granule of one MFMA operand load
+  if (c.dim % kq || c.hidden_dim % kq || c.dim % 16 || c.kv_dim % 16 || c.hidden_dim % 16) return false;
+  if (c.is_quant && m->gshift != 6) return false;
+  return true;
+}
+int ensure_pg_buffers(kh_model* m) {
+  if (m->pg_x) return KH_OK;
+  const kh_config& c = m->cfg;
+  const size_t T = KH_PG_TMAX;
+  int rc;
+  auto zalloc = [&](float** p, size_t n) -> int {
+    if ((rc = dalloc(p, n)) != KH_OK) return rc;
+    // rows beyond the valid tokens are read as MFMA operands (their columns are discarded):
+    // they must hold finite numbers
+    return (int)hipMemsetAsync(*p, 0, n * sizeof(float), m->stream);
+  };
+  if ((rc = zalloc(&m->pg_x, T * c.dim)) != KH_OK) return rc;
+  if ((rc = zalloc(&m->pg_xn, T * c.dim)) != KH_OK) return rc;
+  if ((rc = zalloc(&m->pg_q, T * c.dim)) != KH_OK) return rc;
+  if ((rc = zalloc(&m->pg_att, T * c.dim)) != KH_OK) return rc;
+  if ((rc = zalloc(&m->pg_h, T * c.hidden_dim)) != KH_OK) return rc;
+  m->pg_ws_tok_bytes = (attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride) + 255) & ~(size_t)255;
+  if (m->pg_ws_tok_bytes) {
+    KH_CHECK_HIP(hipMalloc(&m->pg_ws, m->pg_ws_tok_bytes * T));
+    KH_CHECK_HIP(hipMemsetAsync(m->pg_ws, 0, m->pg_ws_tok_bytes * T, m->stream));
+  }
+  return KH_OK;
+}
+// waves splitting K per 16-row tile: enough waves to put ~2 on every SIMD (2048), at least 4
+// operand blocks each, at most KH_PG_WG_MAX threads per workgroup
+int pg_ksplit(int tiles, int nm, int kblocks) {
+  int ks = 1;
+  while (ks * 2 * nm * 64 <= KH_PG_WG_MAX && (long)tiles * nm * ks < 2048 && kblocks / (ks * 2) >= 4) ks *= 2;
+  return ks;
+}
+template <bool Q, int EPI>
+void pg_launch_nt(int nt, int tiles, int wg, hipStream_t s, const KhPgGemmArgs& a) {
+  const size_t lds = pg_lds_bytes(wg / 64, nt);
+  auto go = [&](auto kern) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(wg), lds, s, a);
+  };
+  if (nt > 4) go(k_pg_gemm<Q, 8, EPI>);
+  else if (nt > 2) go(k_pg_gemm<Q, 4, EPI>);
+  else if (nt > 1) go(k_pg_gemm<Q, 2, EPI>);
+  else go(k_pg_gemm<Q, 1, EPI>);
+}
+template <int EPI>
+void pg_launch(kh_model* m, int rows_total, const KhPgGemmArgs& a) {
+  const bool q = m->cfg.is_quant;
+  const int nm = EPI == KH_PG_SWIGLU ? 2 : 1;
+  const int tiles = rows_total / 16;
+  const int ks = pg_ksplit(tiles, nm, a.K / (q ? 64 : 16));
+  const int nt = (a.T + 15) / 16;
+  if (q) pg_launch_nt<true, EPI>(nt, tiles, nm * ks * 64, m->stream, a);
+  else pg_launch_nt<false, EPI>(nt, tiles, nm * ks * 64, m->stream, a);
+}
+// forward of T (<= KH_PG_TMAX) prompt tokens at positions pos0..: fills their K/V cache rows
+void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0) {
+  const kh_config& c = m->cfg;
+  (void)kh_embedding_f32_host(toks, T, m->tok_emb, m->pg_x, c.dim, c.vocab_size, (void*)m->stream);
+  for (int l = 0; l < c.layer_num; ++l) {
+    const LayerW& W = m->layers[l];
+    float* kc = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
+    float* vc = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
+    hipLaunchKernelGGL(k_pg_rmsnorm, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, W.att_norm, m->pg_xn,
+                       c.dim, c.rms_eps);
+    {
+      KhPgGemmArgs a{};
+      a.w[0] = W.wq; a.w[1] = W.wk; a.w[2] = W.wv;
+      a.B = m->pg_xn; a.out = m->pg_q; a.kc = kc; a.vc = vc;
+      a.rows0 = c.dim; a.rows1 = c.kv_dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.pos0 = pos0;
+      a.gshift = m->gshift;
+      pg_launch<KH_PG_QKV>(m, c.dim + 2 * c.kv_dim, a);
+    }
+    hipLaunchKernelGGL(k_pg_rope, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_q, kc, m->sin_cache,
+                       m->cos_cache, c.dim, c.kv_dim, c.head_size, pos0, c.rope_mode);
+    {
+      KhAttnArgs a = fill_attn(m, l);
+      a.q = m->pg_q;
+      a.out = m->pg_att;
+      a.d_pos = nullptr;
+      a.ws = m->pg_ws;
+      a.tok_stride = c.dim;
+      a.ws_tok_bytes = m->pg_ws_tok_bytes;
+      launch_attn_decode(a, pos0, m->attn_wg, m->stream, T);
+    }
+    {
+      KhPgGemmArgs a{};
+      a.w[0] = W.wo;
+      a.B = m->pg_att; a.out = m->pg_x;
+      a.rows0 = c.dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
+      pg_launch<KH_PG_RESID>(m, c.dim, a);
+    }
+    hipLaunchKernelGGL(k_pg_rmsnorm, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, W.ffn_norm, m->pg_xn,
+                       c.dim, c.rms_eps);
+    {
+      KhPgGemmArgs a{};
+      a.w[0] = W.w1; a.w[1] = W.w3;
+      a.B = m->pg_xn; a.out = m->pg_h;
+      a.rows0 = c.hidden_dim; a.ldo = c.hidden_dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
+      pg_launch<KH_PG_SWIGLU>(m, c.hidden_dim, a);
+    }
+    {
+      KhPgGemmArgs a{};
+      a.w[0] = W.w2;
+      a.B = m->pg_h; a.out = m->pg_x;
+      a.rows0 = c.dim; a.ldo = c.dim; a.K = c.hidden_dim; a.T = T; a.gshift = m->gshift;
+      pg_launch<KH_PG_RESID>(m, c.dim, a);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0) {
+  if (!m || !h_tokens || n <= 0 || pos0 < 0) return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if ((int64_t)pos0 + n > c.cache_len) return KH_ERR_RANGE;
+  for (int i = 0; i < n; ++i)
+    if (h_tokens[i] < 0 || h_tokens[i] >= c.vocab_size) return KH_ERR_RANGE;
+  if (!pg_supported(m)) return KH_ERR_UNSUPPORTED;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  int rc;
+  if ((rc = ensure_pg_buffers(m)) != KH_OK) return rc;
+  for (int t0 = 0; t0 < n; t0 += KH_PG_TMAX)
+    launch_prefill_gemm_chunk(m, h_tokens + t0, n - t0 < KH_PG_TMAX ? n - t0 : KH_PG_TMAX, pos0 + t0);
+  return kh_launch_status();
+}
+
 extern "C" int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0) {
   if (!m || !h_tokens || n <= 0 || pos0 < 0) return KH_ERR_INVALID_ARG;
   const kh_config& c = m->cfg;
@@ -1242,8 +1383,14 @@ extern "C" int kh_model_time_prefill(kh_model* m, const int32_t* h_tokens, int32
     KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
     if ((rc = kh_model_prefill(m, h_tokens, n, pos0)) != KH_OK) return rc;
     KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+  } else if (mode == KH_PREFILL_GEMM) {
+    if (!pg_supported(m)) return KH_ERR_UNSUPPORTED;
+    if ((rc = ensure_pg_buffers(m)) != KH_OK) return rc;
+    KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+    if ((rc = kh_model_prefill_gemm(m, h_tokens, n, pos0)) != KH_OK) return rc;
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
   } else {
-    return KH_ERR_UNSUPPORTED;
+    return KH_ERR_INVALID_ARG;
   }
   KH_CHECK_HIP(hipEventSynchronize(m->ev1));
   KH_CHECK_HIP(hipEventElapsedTime(h_ms, m->ev0, m->ev1));
@@ -1320,9 +1467,20 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   // prompt token.  KH_PREFILL=0 keeps the reference's one-token-per-step prompt phase.
   int start = 0;
   KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
-  if (n_prompt - 1 >= 2 && n_prompt - 1 < total_steps && prefill_supported(m)) {
-    if ((rc = kh_model_prefill(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
-    start = n_prompt - 1;
+  if (n_prompt - 1 >= 2 && n_prompt - 1 < total_steps) {
+    // KH_PREFILL: "0" = the reference's token-by-token prompt phase, "gemv" = the bit-identical
+    // B-token kernels, "gemm" = the MFMA GEMM path; default: GEMM from KH_PG_MIN_TOKENS fed-only
+    // tokens on (fp32 tolerance), the B-token kernels below that
+    const char* e = getenv("KH_PREFILL");
+    const bool want_gemm = e ? !strcmp(e, "gemm") : n_prompt - 1 >= KH_PG_MIN_TOKENS;
+    const bool want_gemv = e ? strcmp(e, "0") != 0 : true;
+    if (want_gemm && pg_supported(m)) {
+      if ((rc = kh_model_prefill_gemm(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
+      start = n_prompt - 1;
+    } else if (want_gemv && prefill_supported(m)) {
+      if ((rc = kh_model_prefill(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
+      start = n_prompt - 1;
+    }
   }
   set_state(m, h_prompt[start], start);
   auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps

@@ -141,6 +141,14 @@ class KuiperModel:
         _ffi.check(_ffi.lib().kh_model_prefill(self._h, t, len(tokens), pos0), "kh_model_prefill")
         torch.cuda.synchronize()
 
+    def prefill_gemm(self, tokens: Sequence[int], pos0: int = 0) -> None:
+        """Forward of `tokens` at positions pos0.. as fp32-MFMA GEMMs (up to 128 tokens per weight
+        pass); K/V rows equal the token-by-token ones to fp32 round-off."""
+        t = (C.c_int32 * len(tokens))(*[int(x) for x in tokens])
+        _ffi.check(_ffi.lib().kh_model_prefill_gemm(self._h, t, len(tokens), pos0),
+                   "kh_model_prefill_gemm")
+        torch.cuda.synchronize()
+
     PREFILL_MODES = {"token": 0, "gemv": 1, "gemm": 2}
 
     def time_prefill(self, tokens: Sequence[int], pos0: int = 0, mode: str = "gemm") -> float:

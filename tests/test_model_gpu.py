@@ -417,3 +417,108 @@ def test_generate_with_long_prompt_uses_prefill_and_matches_oracle(gpu, oracle, 
     got0, _ = m.generate(prompt, steps)
     assert got0 == want
     m.close()
+
+
+# ---------------------------------------------------------------- GEMM prefill (kh_gemm.h)
+# fp32-MFMA GEMMs, up to 128 prompt tokens per weight pass: parity is the fp32 tolerance against
+# the ORACLE (not bit-identity with the decode kernels): K/V rows 5e-6, following logits 2e-5
+# (int8: the stated int8 tolerances), same greedy tokens.
+KV_ATOL_GEMM = 5e-6
+
+
+def _oracle_kv_after(oracle, img_h, spec, toks, cache_len=None):
+    kw = {"cache_len": cache_len} if cache_len else {}
+    om = oracle.OracleModel.from_spec(img_h, spec, **kw)
+    for i, t in enumerate(toks):
+        om.forward(int(t), i)
+    return om
+
+
+@pytest.mark.parametrize("name", sorted(_PF_SPECS))
+def test_gemm_prefill_matches_oracle(gpu, oracle, name):
+    """kh_model_prefill_gemm vs the CPU oracle fed the same tokens one by one: cache rows of every
+    layer, the logits of the step that follows and the tokens of a greedy continuation; token
+    counts that leave partial MFMA token tiles (5, 37), fill one pass exactly (128) and need two
+    passes with a non-zero start position (150, then 41 more)."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = _PF_SPECS[name]
+    img_d, img_h = _synth(spec, 77, gpu)
+    rng = np.random.default_rng(9)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, 200)]
+    kv_atol = KV_ATOL_GEMM * (4 if spec.quant else 1)
+    for n, extra in ((5, 0), (37, 0), (128, 0), (150, 41)):
+        m = KuiperModel.from_device_image(img_d, spec)
+        m.prefill_gemm(toks[:n], 0)
+        if extra:
+            m.prefill_gemm(toks[n:n + extra], n)
+        n += extra
+        om = _oracle_kv_after(oracle, img_h, spec, toks[:n])
+        ko, vo = om.kv_cache()
+        for layer in range(spec.n_layers):
+            kg, vg = m.read_kv(layer, 0, n)
+            np.testing.assert_allclose(kg, ko[layer, :n], rtol=0, atol=kv_atol, err_msg=f"{name} n={n} K l{layer}")
+            np.testing.assert_allclose(vg, vo[layer, :n], rtol=0, atol=kv_atol, err_msg=f"{name} n={n} V l{layer}")
+        nxt = m.predict(toks[n], n, exec="fused")
+        lo = om.forward(toks[n], n)
+        np.testing.assert_allclose(m.logits(), lo, rtol=0, atol=_atol(spec))
+        assert nxt == int(np.argmax(lo))
+        m.close()
+
+
+@pytest.mark.parametrize("name", ["gqa-half", "int8"])
+def test_generate_long_prompt_takes_gemm_prefill(gpu, oracle, name, monkeypatch):
+    """Prompts with >= 16 fed-only tokens go through the GEMM prefill inside generate(); the words
+    equal the oracle's and the other two prompt phases' (KH_PREFILL=gemv / 0)."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = _PF_SPECS[name]
+    img_d, img_h = _synth(spec, 77, gpu)
+    rng = np.random.default_rng(3)
+    prompt = [int(t) for t in rng.integers(0, spec.vocab_size, 140)]
+    steps = 200
+    want = oracle.OracleModel.from_spec(img_h, spec).generate(prompt, steps)
+    m = KuiperModel.from_device_image(img_d, spec)
+    got, _ = m.generate(prompt, steps)
+    if got != want:
+        _fail_with_margin(oracle, img_h, spec, prompt, got, want)
+    for mode in ("gemm", "gemv", "0"):
+        monkeypatch.setenv("KH_PREFILL", mode)
+        assert m.generate(prompt, steps)[0] == want, mode
+    m.close()
+
+
+@pytest.mark.parametrize("preset", ["llama3.2-1b", "llama2-7b-int8"])
+def test_gemm_prefill_full_size(gpu, oracle, preset):
+    """Full BASELINE shapes, 128 prompt tokens in one weight pass: K/V rows of the first and last
+    layer against the oracle (Llama-3.2-1B) / against the bit-exact B-token path (7B int8, whose
+    oracle pass would take minutes), and the same next token."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.PRESETS[preset]
+    img_d, img_h = _synth(spec, 4321, gpu)
+    rng = np.random.default_rng(1)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, 129)]
+    n = 128
+    a = KuiperModel.from_device_image(img_d, spec, max_seq_len=256)
+    a.prefill_gemm(toks[:n], 0)
+    layers = (0, spec.n_layers - 1)
+    ka = [a.read_kv(l, 0, n) for l in layers]
+    na = a.predict(toks[n], n, exec="fused")
+    la = a.logits().copy()
+    a.close()
+    if not spec.quant:
+        om = _oracle_kv_after(oracle, img_h, spec, toks[:n], cache_len=256)
+        ko, vo = om.kv_cache()
+        ref = [(ko[l, :n], vo[l, :n]) for l in layers]
+        lo = om.forward(toks[n], n)
+    else:
+        b = KuiperModel.from_device_image(img_d, spec, max_seq_len=256)
+        b.prefill(toks[:n], 0)
+        ref = [b.read_kv(l, 0, n) for l in layers]
+        b.predict(toks[n], n, exec="fused")
+        lo = b.logits().copy()
+        b.close()
+    tol = KV_ATOL_GEMM * (4 if spec.quant else 1)
+    for (k1, v1), (k2, v2) in zip(ka, ref):
+        np.testing.assert_allclose(k1, k2, rtol=0, atol=tol)
+        np.testing.assert_allclose(v1, v2, rtol=0, atol=tol)
+    np.testing.assert_allclose(la, lo, rtol=0, atol=_atol(spec) * 2)
+    assert na == int(np.argmax(lo))
