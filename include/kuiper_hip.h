@@ -288,6 +288,32 @@ int kh_spm_encode(const kh_spm* t, const char* utf8, int64_t len, int32_t add_bo
 int kh_spm_decode(const kh_spm* t, const int32_t* ids, int32_t n, char* out_utf8, int64_t cap,
                   int64_t* out_len);
 
+/* ---- Tokenizer: byte-level BPE over a HuggingFace tokenizer.json (host only) ---------------------
+ * Replaces op::BpeEncodeLayer (Llama-3.x) and op::QwenEncodeLayer (Qwen2.5)
+ * (kuiper/source/op/encode.cpp:59-183) together with what they link: nlohmann::json, the vendored
+ * tiktoken.h (kuiper/include/base/tiktoken.h:17-268), RE2 (the pre-split pattern PAT_STR,
+ * encode.cpp:59-60), abseil and the vendored Unicode tables.  `flavor` selects which added_tokens
+ * are BOS / EOS / second stop id (encode.cpp:97-103: <|begin_of_text|>, <|end_of_text|>, <|eot_id|>;
+ * :170-176: <|im_start|>, <|im_end|>, <|endoftext|>); a name the file lacks is reported as -1.
+ * KH_BPE_REF_SPACES reproduces the reference's " " -> "Ġ" replacement before encoding and its
+ * inverse after decoding (encode.cpp:108-111, 124-126); without it the text is encoded as it is,
+ * which is what HF `tokenizers` produces for the same pattern.  Model::encode adds BOS for Llama and
+ * not for Qwen (model.cpp:158-165): that is the caller's add_bos.  Return codes as kh_spm_*. */
+typedef struct kh_bpe kh_bpe;
+enum { KH_BPE_LLAMA3 = 0, KH_BPE_QWEN2 = 1 };
+enum { KH_BPE_REF_SPACES = 1 };
+int kh_bpe_create_from_file(const char* tokenizer_json_path, int32_t flavor, kh_bpe** out);
+int kh_bpe_create_from_memory(const void* tokenizer_json, int64_t nbytes, int32_t flavor, kh_bpe** out);
+void kh_bpe_destroy(kh_bpe* t);
+int32_t kh_bpe_vocab_size(const kh_bpe* t); /* |model.vocab| + |added_tokens| (encode.cpp:105) */
+int32_t kh_bpe_bos_id(const kh_bpe* t);
+int32_t kh_bpe_eos_id(const kh_bpe* t);
+int32_t kh_bpe_stop_id(const kh_bpe* t, int32_t which); /* 0, 1: is_sentence_ending (encode.cpp:130-136) */
+int kh_bpe_encode(const kh_bpe* t, const char* utf8, int64_t len, int32_t add_bos, int32_t add_eos,
+                  int32_t flags, int32_t* out_ids, int32_t cap, int32_t* n_ids);
+int kh_bpe_decode(const kh_bpe* t, const int32_t* ids, int32_t n, int32_t flags, char* out_utf8,
+                  int64_t cap, int64_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,8 @@ EXPORTS = [
     "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
     "kh_spm_create_from_file", "kh_spm_create_from_memory", "kh_spm_destroy", "kh_spm_vocab_size",
     "kh_spm_bos_id", "kh_spm_eos_id", "kh_spm_unk_id", "kh_spm_encode", "kh_spm_decode",
+    "kh_bpe_create_from_file", "kh_bpe_create_from_memory", "kh_bpe_destroy", "kh_bpe_vocab_size",
+    "kh_bpe_bos_id", "kh_bpe_eos_id", "kh_bpe_stop_id", "kh_bpe_encode", "kh_bpe_decode",
     "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
 ]
 
@@ -125,6 +127,17 @@ def lib() -> C.CDLL:
     L.kh_spm_encode.argtypes = [_vp, C.c_char_p, C.c_int64, _i32, _i32, C.POINTER(_i32), _i32,
                                 C.POINTER(_i32)]
     L.kh_spm_decode.argtypes = [_vp, C.POINTER(_i32), _i32, C.c_char_p, C.c_int64,
+                                C.POINTER(C.c_int64)]
+    L.kh_bpe_create_from_file.argtypes = [C.c_char_p, _i32, C.POINTER(_vp)]
+    L.kh_bpe_create_from_memory.argtypes = [_vp, C.c_int64, _i32, C.POINTER(_vp)]
+    L.kh_bpe_destroy.argtypes = [_vp]
+    L.kh_bpe_destroy.restype = None
+    for fn in (L.kh_bpe_vocab_size, L.kh_bpe_bos_id, L.kh_bpe_eos_id):
+        fn.argtypes = [_vp]
+    L.kh_bpe_stop_id.argtypes = [_vp, _i32]
+    L.kh_bpe_encode.argtypes = [_vp, C.c_char_p, C.c_int64, _i32, _i32, _i32, C.POINTER(_i32), _i32,
+                                C.POINTER(_i32)]
+    L.kh_bpe_decode.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, C.c_char_p, C.c_int64,
                                 C.POINTER(C.c_int64)]
     L.kh_model_prefill.argtypes = [_vp, C.POINTER(_i32), _i32, _i32]
     L.kh_model_prefill_gemm.argtypes = [_vp, C.POINTER(_i32), _i32, _i32]

@@ -38,7 +38,7 @@
 
 #define KH_PG_TMAX 128           // prompt tokens per weight pass (8 MFMA token tiles)
 #define KH_PG_WG_MAX 512         // <= 8 waves per workgroup: 256 VGPRs per lane stay available
-#define KH_PG_RING 8             // weight blocks in flight per wave
+#define KH_PG_RING 8             // weight blocks per register ring (two rings per wave)
 
 enum { KH_PG_QKV = 0, KH_PG_RESID = 1, KH_PG_SWIGLU = 2 };
 
@@ -56,108 +56,130 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// K loop of one wave, fp32 weights: blocks [b0, b1) of 16 columns
-template <int NT>
-__device__ __forceinline__ void pg_kloop_f32(const float* __restrict__ wrow /* row i, + 4h */,
-                                             const float* __restrict__ brow /* token i, + 4h */,
-                                             size_t tile_stride /* 16 * K floats */, int b0, int b1,
-                                             f32x4 (&acc)[NT]) {
-  f32x4 a[KH_PG_RING];
+// ---- K loops -------------------------------------------------------------------------------------
+// A wave has ONE in-order counter for its vector-memory loads (s_waitcnt vmcnt): a wait for a young
+// L2-latency load (the activation operand of the next block) also waits for every OLDER load, in
+// particular for HBM-latency weight loads issued before it.  A ring that refills one weight block
+// per iteration therefore stalls every iteration for an HBM round trip.  Here the weights arrive in
+// PHASES: two register rings of KH_PG_RING blocks; while ring `cur` is consumed, ring `nxt` is
+// requested in ONE batch right behind the first activation prefetch of the phase, so its latency
+// is exposed at most once per phase (8 blocks = 8 k MFMA cycles at 8 token tiles) instead of once
+// per block, and only for what exceeds the two iterations that run before the next young load is
+// awaited.
+// The activation operand ping-pongs between two register sets xb[0] / xb[1] (no copies: a copy
+// would make the compiler wait for the prefetch as soon as it is issued).
+template <int NT, int SUB /* operand sub-steps per block: 1 fp32, 4 int8 */, class LoadA, class LoadB,
+          class Mfma>
+__device__ __forceinline__ void pg_phases(int b0, int b1, LoadA&& load_a, LoadB&& load_b,
+                                          Mfma&& mfma_sub) {
+  static_assert((KH_PG_RING * SUB) % 2 == 0, "ping-pong parity must restart with every phase");
   const int last = b1 - 1;
+  load_a(0, b0);  // ring 0 <- blocks b0 .. b0+R-1
+  f32x4 xb[2][NT];
+  load_b(xb[0], b0, 0);
+  for (int b = b0; b < b1; b += 2 * KH_PG_RING) {
 #pragma unroll
-  for (int d = 0; d < KH_PG_RING; ++d) {
-    const int bb = b0 + d < last ? b0 + d : last;
-    a[d] = ld_nt((const f32x4*)(wrow + (size_t)bb * 16));
-  }
-  f32x4 xc[NT];
+    for (int ph = 0; ph < 2; ++ph) {
+      const int base = b + ph * KH_PG_RING;
+      if (base < b1) {  // wave-uniform (b0, b1 are scalars)
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) xc[nt] = *(const f32x4*)(brow + nt * tile_stride + (size_t)b0 * 16);
-  for (int b = b0; b < b1; b += KH_PG_RING) {
+        for (int d = 0; d < KH_PG_RING; ++d) {
+          const int bb = base + d;
+          if (bb < b1) {
 #pragma unroll
-    for (int d = 0; d < KH_PG_RING; ++d) {
-      const int bb = b + d;
-      if (bb < b1) {  // wave-uniform
-        const int bn = bb + 1 < last ? bb + 1 : last;
-        f32x4 xn[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xn[nt] = *(const f32x4*)(brow + nt * tile_stride + (size_t)bn * 16);
-        const f32x4 av = a[d];
-        const int br = bb + KH_PG_RING < last ? bb + KH_PG_RING : last;
-        a[d] = ld_nt((const f32x4*)(wrow + (size_t)br * 16));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.x, xc[nt].x, acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.y, xc[nt].y, acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.z, xc[nt].z, acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.w, xc[nt].w, acc[nt]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xc[nt] = xn[nt];
+            for (int q = 0; q < SUB; ++q) {
+              const int cur = (d * SUB + q) & 1;
+              // next sub-step's activations first (young, L2 latency) ...
+              const int nb_ = q + 1 < SUB ? bb : (bb + 1 < last ? bb + 1 : last);
+              load_b(xb[cur ^ 1], nb_, q + 1 < SUB ? q + 1 : 0);
+              // ... then, once per phase, the whole next weight ring (HBM latency)
+              if (d == 0 && q == 0) load_a(1 - ph, base + KH_PG_RING < last ? base + KH_PG_RING : last);
+              __builtin_amdgcn_sched_barrier(0);  // the prefetches are issued before the MFMAs
+              mfma_sub(ph, d, q, xb[cur]);
+            }
+          }
+        }
       }
     }
   }
 }
 
-// K loop, int8 group-64 weights: super blocks [b0, b1) of 64 columns.  Lane (i, h) owns the 16
-// weights W8[i][64sb + 16h .. +16] (one dwordx4, one group -> one scale); quarter qd of them pairs
-// with Xn[token][64sb + 16h + 4qd .. +4].
+// fp32 weights: blocks of 16 columns; lane (i, h) owns W[i][16b + 4h .. +4]
+template <int NT>
+__device__ __forceinline__ void pg_kloop_f32(const float* __restrict__ wrow /* row i, + 4h */,
+                                             const float* __restrict__ brow /* token i, + 4h */,
+                                             size_t tile_stride /* 16 * K floats */, int b0, int b1,
+                                             f32x4 (&acc)[NT]) {
+  f32x4 a[2][KH_PG_RING];
+  const int last = b1 - 1;
+  auto load_a = [&](int ring, int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < KH_PG_RING; ++d) {
+      const int bb = base + d < last ? base + d : last;
+      a[ring][d] = ld_nt((const f32x4*)(wrow + (size_t)bb * 16));
+    }
+  };
+  auto load_b = [&](f32x4 (&x)[NT], int bb, int) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) x[nt] = *(const f32x4*)(brow + nt * tile_stride + (size_t)bb * 16);
+  };
+  auto sub = [&](int ph, int d, int, const f32x4 (&x)[NT]) __attribute__((always_inline)) {
+    const f32x4 av = a[ph][d];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.x, x[nt].x, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.y, x[nt].y, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.z, x[nt].z, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(av.w, x[nt].w, acc[nt]);
+  };
+  pg_phases<NT, 1>(b0, b1, load_a, load_b, sub);
+}
+
+// int8 group-64 weights: blocks of 64 columns.  Lane (i, h) owns the 16 weights
+// W8[i][64b + 16h .. +16] (one dwordx4, one group -> one scale); quarter q of them pairs with
+// Xn[token][64b + 16h + 4q .. +4].
 template <int NT>
 __device__ __forceinline__ void pg_kloop_q8(const int8_t* __restrict__ wrow /* row i, + 16h */,
                                             const float* __restrict__ srow /* scales of row i */,
                                             const float* __restrict__ brow /* token i, + 16h */,
                                             size_t tile_stride, int b0, int b1, f32x4 (&acc)[NT]) {
-  constexpr int RQ = 4;  // super blocks in flight (4 x 64 columns)
-  i32x4 q[RQ];
-  float sc[RQ];
+  i32x4 qw[2][KH_PG_RING];
+  float sc[2][KH_PG_RING];
   const int last = b1 - 1;
+  auto load_a = [&](int ring, int base) __attribute__((always_inline)) {
 #pragma unroll
-  for (int d = 0; d < RQ; ++d) {
-    const int bb = b0 + d < last ? b0 + d : last;
-    q[d] = ld_nt((const i32x4*)(wrow + (size_t)bb * 64));
-    sc[d] = srow[bb];
-  }
-  f32x4 xc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) xc[nt] = *(const f32x4*)(brow + nt * tile_stride + (size_t)b0 * 64);
-  for (int b = b0; b < b1; b += RQ) {
-#pragma unroll
-    for (int d = 0; d < RQ; ++d) {
-      const int bb = b + d;
-      if (bb < b1) {  // wave-uniform
-        const float s = sc[d];
-        const int dw[4] = {q[d].x, q[d].y, q[d].z, q[d].w};
-        const int br = bb + RQ < last ? bb + RQ : last;
-        q[d] = ld_nt((const i32x4*)(wrow + (size_t)br * 64));
-        sc[d] = srow[br];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          // activation operand of the NEXT quarter (next super block after the last quarter)
-          const int nb_ = qd < 3 ? bb : (bb + 1 < last ? bb + 1 : last);
-          const int nq = qd < 3 ? qd + 1 : 0;
-          f32x4 xn[NT];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            xn[nt] = *(const f32x4*)(brow + nt * tile_stride + (size_t)nb_ * 64 + 4 * nq);
-          // dequantised weight = scale * float(w8): the reference's per-element form
-          const float w0 = s * (float)(int8_t)(dw[qd] & 0xff);
-          const float w1 = s * (float)(int8_t)((dw[qd] >> 8) & 0xff);
-          const float w2 = s * (float)(int8_t)((dw[qd] >> 16) & 0xff);
-          const float w3 = s * (float)(dw[qd] >> 24);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w0, xc[nt].x, acc[nt]);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w1, xc[nt].y, acc[nt]);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w2, xc[nt].z, acc[nt]);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w3, xc[nt].w, acc[nt]);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) xc[nt] = xn[nt];
-        }
-      }
+    for (int d = 0; d < KH_PG_RING; ++d) {
+      const int bb = base + d < last ? base + d : last;
+      qw[ring][d] = ld_nt((const i32x4*)(wrow + (size_t)bb * 64));
+      sc[ring][d] = srow[bb];
     }
-  }
+  };
+  auto load_b = [&](f32x4 (&x)[NT], int bb, int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      x[nt] = *(const f32x4*)(brow + nt * tile_stride + (size_t)bb * 64 + 4 * q);
+  };
+  auto sub = [&](int ph, int d, int q, const f32x4 (&x)[NT]) __attribute__((always_inline)) {
+    const float s = sc[ph][d];
+    const i32x4 qv = qw[ph][d];
+    const int dw = q == 0 ? qv.x : (q == 1 ? qv.y : (q == 2 ? qv.z : qv.w));
+    // dequantised weight = scale * float(w8): the reference's per-element form
+    const float w0 = s * (float)(int8_t)(dw & 0xff);
+    const float w1 = s * (float)(int8_t)((dw >> 8) & 0xff);
+    const float w2 = s * (float)(int8_t)((dw >> 16) & 0xff);
+    const float w3 = s * (float)(dw >> 24);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w0, x[nt].x, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w1, x[nt].y, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w2, x[nt].z, acc[nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(w3, x[nt].w, acc[nt]);
+  };
+  pg_phases<NT, 4>(b0, b1, load_a, load_b, sub);
 }
 
 // blockDim.x = NM * ks * 64 (NM = 2 for SWIGLU); blockIdx.x = 16-row tile.
@@ -189,15 +211,19 @@ __global__ __launch_bounds__(KH_PG_WG_MAX) void k_pg_gemm(const KhPgGemmArgs a) 
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (the K range depends on the wave index only: keep it in scalar registers so the block guards
+  // of the K loop are scalar branches)
   if (!QUANT) {
     const int nb = K >> 4;
-    const int b0 = (int)((long)kpart * nb / ks), b1 = (int)((long)(kpart + 1) * nb / ks);
+    const int b0 = __builtin_amdgcn_readfirstlane((int)((long)kpart * nb / ks));
+    const int b1 = __builtin_amdgcn_readfirstlane((int)((long)(kpart + 1) * nb / ks));
     const float* wrow = (const float*)W.w + (size_t)(wr0 + i) * K + 4 * h;
     const float* brow = a.B + (size_t)i * K + 4 * h;
     if (b1 > b0) pg_kloop_f32<NT>(wrow, brow, tile_stride, b0, b1, acc);
   } else {
     const int nb = K >> 6;
-    const int b0 = (int)((long)kpart * nb / ks), b1 = (int)((long)(kpart + 1) * nb / ks);
+    const int b0 = __builtin_amdgcn_readfirstlane((int)((long)kpart * nb / ks));
+    const int b1 = __builtin_amdgcn_readfirstlane((int)((long)(kpart + 1) * nb / ks));
     const int8_t* wrow = (const int8_t*)W.w + (size_t)(wr0 + i) * K + 16 * h;
     const float* srow = W.scales + (size_t)(wr0 + i) * nb;
     const float* brow = a.B + (size_t)i * K + 16 * h;

@@ -1233,7 +1233,8 @@ int pg_ksplit(int tiles, int nm, int kblocks) {
 }
 template <bool Q, int EPI>
 void pg_launch_nt(int nt, int tiles, int wg, hipStream_t s, const KhPgGemmArgs& a) {
-  const size_t lds = pg_lds_bytes(wg / 64, nt);
+  const int NT = nt > 4 ? 8 : (nt > 2 ? 4 : (nt > 1 ? 2 : 1));  // the instantiation's tile count
+  const size_t lds = pg_lds_bytes(wg / 64, NT);
   auto go = [&](auto kern) {
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

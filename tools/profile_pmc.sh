@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/profile_pmc.sh <workload> <out.csv> [extra bench args]
+# usage: tools/profile_pmc.sh <workload> <out.csv> [pmc_workload.py args]
 # Per-kernel utilisation counters of the decode step (and of the GEMM prefill bench.py also runs),
 # separate --pmc passes with --kernel-trace only (gpurun refuses --pmc beside the trace domains).
 # Derived: VALUBusy, MfmaUtil, OccupancyPercent, MemUnitStalled ; the gfx94x "MemUnitBusy" formula
@@ -11,7 +11,7 @@ PASSES=("VALUBusy" "MfmaUtil" "OccupancyPercent" "MemUnitStalled" "TA_BUSY_avr G
         "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT")
 i=0
 for c in "${PASSES[@]}"; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc_$i -o b -- python $R/bench.py --workload $W --steps 8 --warmup 2 --repeats 1 --no-cpu-baseline --secondary "" "$@" > /dev/null 2> $R/gpurun_out/pmc_$i.log
+  timeout 300 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc_$i -o b -- python $R/tools/pmc_workload.py $W "$@" > $R/gpurun_out/pmclog_$i.txt 2>&1 || echo "pass $i ($c) exit $?"
   i=$((i+1))
 done
 cd $R
