@@ -656,18 +656,37 @@ static inline bool attn_group_supported(int head_size, int kv_mul, int wg) {
 }
 // Launch.  a.nsplit_g == 0 disables the group path; head_size > 32 required (callers route
 // smaller heads to the generic LDS-score kernel).
+// pos_hi >= 0 (host-positioned launches only): the highest position among the ntok tokens; the grid
+// then carries only the splits that own timesteps at those positions instead of all cache_len / 256
+// of them (a 128-token prefill slice at the start of a 131072-row cache launched 16x too many
+// workgroups, all of which left immediately - measured 129 us per layer of dispatch).
 static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStream_t s,
-                                      int ntok = 1) {
+                                      int ntok = 1, int pos_hi = -1) {
   const int G = attn_lanes(a.head_size);
   const bool grp = a.nsplit_g > 0 && attn_group_supported(a.head_size, a.kv_mul, wg);
   if (!grp) a.nsplit_g = 0;
-  int grid = a.kv_heads * a.kv_mul * a.nsplit;
+  int head_splits = a.nsplit, group_splits = grp ? a.nsplit_g : 0;
+  if (pos_hi >= 0 && !a.d_pos) {
+    head_splits = 0;
+    group_splits = 0;
+    for (int p = host_pos; p <= pos_hi; ++p) {
+      if (grp && p + 1 >= a.t_long) {
+        const int n = attn_active_splits(p, a.nsplit_g);
+        if (n > group_splits) group_splits = n;
+      } else {
+        const int n = attn_active_splits(p, a.nsplit);
+        if (n > head_splits) head_splits = n;
+      }
+    }
+  }
+  int grid = a.kv_heads * a.kv_mul * head_splits;
   size_t lds = attn_fast_lds_bytes(a.head_size, wg);
   if (grp) {
-    if (a.kv_heads * a.nsplit_g > grid) grid = a.kv_heads * a.nsplit_g;
+    if (a.kv_heads * group_splits > grid) grid = a.kv_heads * group_splits;
     const size_t l2 = attn_group_lds_bytes(a.head_size, a.kv_mul);
     if (l2 > lds) lds = l2;
   }
+  if (grid < 1) grid = 1;
 #define KH_ATTN_LAUNCH(GG, KK) \
   hipLaunchKernelGGL((k_attn_decode<GG, KK>), dim3(grid, ntok), dim3(wg), lds, s, a, host_pos)
   const int kvm = grp ? a.kv_mul : 0;

@@ -1167,7 +1167,7 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
       a.ws = m->pf_ws;
       a.tok_stride = c.dim;
       a.ws_tok_bytes = m->pf_ws_tok_bytes;
-      launch_attn_decode(a, pos0, m->attn_wg, m->stream, nvalid);
+      launch_attn_decode(a, pos0, m->attn_wg, m->stream, nvalid, pos0 + nvalid - 1);
     }
     pf_gemv_res(m, m->sh_wo, W.wo, m->pf_att, m->pf_x, c.dim, c.dim, nvalid, B);
     {
@@ -1224,54 +1224,80 @@ int ensure_pg_buffers(kh_model* m) {
   }
   return KH_OK;
 }
-// waves splitting K per 16-row tile: enough waves to put ~2 on every SIMD (2048), at least 4
-// operand blocks each, at most KH_PG_WG_MAX threads per workgroup
-int pg_ksplit(int tiles, int nm, int kblocks) {
-  int ks = 1;
-  while (ks * 2 * nm * 64 <= KH_PG_WG_MAX && (long)tiles * nm * ks < 2048 && kblocks / (ks * 2) >= 4) ks *= 2;
-  return ks;
+// Launch shape of one prefill GEMM (kh_gemm.h): R 16-row tiles and NT 16-token tiles per wave,
+// ks waves splitting K per workgroup, grid.y token slices.
+//   * R = 2 (each activation fragment feeds two weight tiles) whenever every matrix has a multiple
+//     of 32 rows; token slices of 64 instead of 128 when the GEMM has too few row tiles to put a
+//     wave on every SIMD otherwise;
+//   * ks: enough waves for ~1-2 per SIMD, at least two weight rings of work each, <= 8 waves per
+//     workgroup.
+struct PgShape {
+  int R, NT, ks, slices;
+};
+PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int ring_blocks) {
+  PgShape sh;
+  sh.R = r2_ok ? 2 : 1;
+  const int tiles = rows_total / (16 * sh.R);
+  const int nt_all = (T + 15) / 16;
+  if (nt_all <= 4) {
+    sh.NT = 4;
+    sh.slices = 1;
+  } else if ((long)tiles * nm >= 512 && sh.R == 2) {
+    sh.NT = 8;  // many row tiles: one slice of 128 tokens, weights stream exactly once
+    sh.slices = 1;
+  } else {
+    sh.NT = 4;
+    sh.slices = (nt_all + 3) / 4;
+  }
+  sh.ks = 1;
+  while (sh.ks * 2 * nm * 64 <= KH_PG_WG_MAX && (long)tiles * sh.slices * nm * sh.ks < 1536 &&
+         kblocks / (sh.ks * 2) >= 2 * ring_blocks)
+    sh.ks *= 2;
+  return sh;
 }
 template <bool Q, int EPI>
-void pg_launch_nt(int nt, int tiles, int wg, hipStream_t s, const KhPgGemmArgs& a) {
-  const int NT = nt > 4 ? 8 : (nt > 2 ? 4 : (nt > 1 ? 2 : 1));  // the instantiation's tile count
-  const size_t lds = pg_lds_bytes(wg / 64, NT);
+void pg_launch_cfg(const PgShape& sh, int tiles, int wg, hipStream_t s, const KhPgGemmArgs& a) {
+  const size_t lds = pg_lds_bytes(wg / 64, sh.NT);
   auto go = [&](auto kern) {
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(wg), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles, sh.slices), dim3(wg), lds, s, a);
   };
-  if (nt > 4) go(k_pg_gemm<Q, 8, EPI>);
-  else if (nt > 2) go(k_pg_gemm<Q, 4, EPI>);
-  else if (nt > 1) go(k_pg_gemm<Q, 2, EPI>);
-  else go(k_pg_gemm<Q, 1, EPI>);
+  if (sh.R == 2 && sh.NT == 8) go(k_pg_gemm<Q, 2, 8, EPI>);
+  else if (sh.R == 2) go(k_pg_gemm<Q, 2, 4, EPI>);
+  else go(k_pg_gemm<Q, 1, 4, EPI>);
 }
 template <int EPI>
-void pg_launch(kh_model* m, int rows_total, const KhPgGemmArgs& a) {
+void pg_launch(kh_model* m, int rows_total, bool r2_ok, const KhPgGemmArgs& a) {
   const bool q = m->cfg.is_quant;
   const int nm = EPI == KH_PG_SWIGLU ? 2 : 1;
-  const int tiles = rows_total / 16;
-  const int ks = pg_ksplit(tiles, nm, a.K / (q ? 64 : 16));
-  const int nt = (a.T + 15) / 16;
-  if (q) pg_launch_nt<true, EPI>(nt, tiles, nm * ks * 64, m->stream, a);
-  else pg_launch_nt<false, EPI>(nt, tiles, nm * ks * 64, m->stream, a);
+  PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 2 : 4);
+  if (sh.R == 1 && sh.NT == 8) sh.NT = 4, sh.slices = 2;  // (1, 8) is not instantiated
+  const int tiles = rows_total / (16 * sh.R);
+  if (q) pg_launch_cfg<true, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a);
+  else pg_launch_cfg<false, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a);
 }
 // forward of T (<= KH_PG_TMAX) prompt tokens at positions pos0..: fills their K/V cache rows
 void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0) {
   const kh_config& c = m->cfg;
+  const bool q = c.is_quant;
   (void)kh_embedding_f32_host(toks, T, m->tok_emb, m->pg_x, c.dim, c.vocab_size, (void*)m->stream);
+  auto rmsnorm = [&](const float* w) {
+    if (q) hipLaunchKernelGGL(k_pg_rmsnorm<true>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps);
+    else hipLaunchKernelGGL(k_pg_rmsnorm<false>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps);
+  };
   for (int l = 0; l < c.layer_num; ++l) {
     const LayerW& W = m->layers[l];
     float* kc = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
     float* vc = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
-    hipLaunchKernelGGL(k_pg_rmsnorm, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, W.att_norm, m->pg_xn,
-                       c.dim, c.rms_eps);
+    rmsnorm(W.att_norm);
     {
       KhPgGemmArgs a{};
       a.w[0] = W.wq; a.w[1] = W.wk; a.w[2] = W.wv;
-      a.B = m->pg_xn; a.out = m->pg_q; a.kc = kc; a.vc = vc;
+      a.B = m->pg_xn; a.b_tiled = 1; a.out = m->pg_q; a.kc = kc; a.vc = vc;
       a.rows0 = c.dim; a.rows1 = c.kv_dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.pos0 = pos0;
       a.gshift = m->gshift;
-      pg_launch<KH_PG_QKV>(m, c.dim + 2 * c.kv_dim, a);
+      pg_launch<KH_PG_QKV>(m, c.dim + 2 * c.kv_dim, c.dim % 32 == 0 && c.kv_dim % 32 == 0, a);
     }
     hipLaunchKernelGGL(k_pg_rope, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_q, kc, m->sin_cache,
                        m->cos_cache, c.dim, c.kv_dim, c.head_size, pos0, c.rope_mode);
@@ -1283,30 +1309,29 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       a.ws = m->pg_ws;
       a.tok_stride = c.dim;
       a.ws_tok_bytes = m->pg_ws_tok_bytes;
-      launch_attn_decode(a, pos0, m->attn_wg, m->stream, T);
+      launch_attn_decode(a, pos0, m->attn_wg, m->stream, T, pos0 + T - 1);
     }
     {
       KhPgGemmArgs a{};
       a.w[0] = W.wo;
-      a.B = m->pg_att; a.out = m->pg_x;
+      a.B = m->pg_att; a.b_tiled = 0; a.out = m->pg_x;  // the attention kernel writes row-major rows
       a.rows0 = c.dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
-      pg_launch<KH_PG_RESID>(m, c.dim, a);
+      pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
     }
-    hipLaunchKernelGGL(k_pg_rmsnorm, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, W.ffn_norm, m->pg_xn,
-                       c.dim, c.rms_eps);
+    rmsnorm(W.ffn_norm);
     {
       KhPgGemmArgs a{};
       a.w[0] = W.w1; a.w[1] = W.w3;
-      a.B = m->pg_xn; a.out = m->pg_h;
+      a.B = m->pg_xn; a.b_tiled = 1; a.out = m->pg_h;
       a.rows0 = c.hidden_dim; a.ldo = c.hidden_dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
-      pg_launch<KH_PG_SWIGLU>(m, c.hidden_dim, a);
+      pg_launch<KH_PG_SWIGLU>(m, c.hidden_dim, c.hidden_dim % 32 == 0, a);
     }
     {
       KhPgGemmArgs a{};
       a.w[0] = W.w2;
-      a.B = m->pg_h; a.out = m->pg_x;
+      a.B = m->pg_h; a.b_tiled = 1; a.out = m->pg_x;
       a.rows0 = c.dim; a.ldo = c.dim; a.K = c.hidden_dim; a.T = T; a.gshift = m->gshift;
-      pg_launch<KH_PG_RESID>(m, c.dim, a);
+      pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
     }
   }
 }
