@@ -43,6 +43,13 @@
 #include "kh_fused.h"
 
 #define KH_PG_TMAX 128           // prompt tokens per weight pass (8 MFMA token tiles)
+// ablation switches (tools/exp_gemm.sh builds variants that compute WRONG results on purpose):
+#ifndef KH_PG_EXP_NOA
+#define KH_PG_EXP_NOA 0          // weight operand loaded once per wave instead of streamed
+#endif
+#ifndef KH_PG_EXP_NOB
+#define KH_PG_EXP_NOB 0          // activation operand loaded once per wave instead of streamed
+#endif
 #define KH_PG_WG_MAX 512         // <= 8 waves per workgroup: 256 VGPRs per lane stay available
 
 enum { KH_PG_QKV = 0, KH_PG_RESID = 1, KH_PG_SWIGLU = 2 };
@@ -126,22 +133,32 @@ struct PgBAddr {           // activation operand addressing: base + nt*s_nt + bl
 template <int R, int NT>
 __device__ __forceinline__ void pg_kloop_f32(const float* const (&wrow)[R], const PgBAddr& B, int b0,
                                              int b1, f32x4 (&acc)[R][NT]) {
-  constexpr int RING = 8 / R;
+  constexpr int RING = (R == 2 && NT >= 4) ? 4 : 8;  // blocks per weight ring (register budget)
   f32x4 a[2][RING][R];
   f32x4 xb[2][NT];
   const int last = b1 - 1;
+  bool first_a = true, first_b = true;
   auto load_a = [&](int ring, int base) __attribute__((always_inline)) {
+    if (KH_PG_EXP_NOA && !first_a) return;
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
       const int bb = base + d < last ? base + d : last;
 #pragma unroll
-      for (int r = 0; r < R; ++r) a[ring][d][r] = ld_nt((const f32x4*)(wrow[r] + (size_t)bb * 16));
+      for (int r = 0; r < R; ++r) {
+        a[ring][d][r] = ld_nt((const f32x4*)(wrow[r] + (size_t)bb * 16));
+        if (KH_PG_EXP_NOA) a[1 - ring][d][r] = a[ring][d][r];
+      }
     }
+    first_a = false;
   };
   auto load_b = [&](int set, int bb, int) __attribute__((always_inline)) {
+    if (KH_PG_EXP_NOB && !first_b) return;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
       xb[set][nt] = *(const f32x4*)(B.base + nt * B.s_nt + (size_t)bb * B.s_b);
+      if (KH_PG_EXP_NOB) xb[1 - set][nt] = xb[set][nt];
+    }
+    first_b = false;
   };
   auto sub = [&](int ph, int d, int, int set) __attribute__((always_inline)) {
 #pragma unroll

@@ -1225,35 +1225,41 @@ int ensure_pg_buffers(kh_model* m) {
   return KH_OK;
 }
 // Launch shape of one prefill GEMM (kh_gemm.h): R 16-row tiles and NT 16-token tiles per wave,
-// ks waves splitting K per workgroup, grid.y token slices.
-//   * R = 2 (each activation fragment feeds two weight tiles) whenever every matrix has a multiple
-//     of 32 rows; token slices of 64 instead of 128 when the GEMM has too few row tiles to put a
-//     wave on every SIMD otherwise;
-//   * ks: enough waves for ~1-2 per SIMD, at least two weight rings of work each, <= 8 waves per
-//     workgroup.
+// ks waves splitting K per workgroup, grid.y token slices.  A workgroup lives on ONE CU, so what
+// matters first is that the launch has a whole number of workgroups per CU (a 128-workgroup launch
+// of 8-wave groups leaves half the chip idle: measured on the 1B wo / w2 GEMMs); among the shapes
+// that fill the chip equally well the largest register tile wins (fewest operand bytes per MFMA).
 struct PgShape {
   int R, NT, ks, slices;
 };
 PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int ring_blocks) {
-  PgShape sh;
-  sh.R = r2_ok ? 2 : 1;
-  const int tiles = rows_total / (16 * sh.R);
   const int nt_all = (T + 15) / 16;
-  if (nt_all <= 4) {
-    sh.NT = 4;
-    sh.slices = 1;
-  } else if ((long)tiles * nm >= 512 && sh.R == 2) {
-    sh.NT = 8;  // many row tiles: one slice of 128 tokens, weights stream exactly once
-    sh.slices = 1;
-  } else {
-    sh.NT = 4;
-    sh.slices = (nt_all + 3) / 4;
+  static const int cand[4][2] = {{2, 8}, {2, 4}, {2, 2}, {1, 4}};
+  PgShape best{1, 4, 1, (nt_all + 3) / 4};
+  double best_eff = -1.0;
+  for (const auto& c : cand) {
+    const int R = c[0], NT = c[1];
+    if (R == 2 && !r2_ok) continue;
+    if (NT > 4 && nt_all <= 4) continue;  // no point in a 128-token tile for <= 64 tokens
+    if (NT > 2 && nt_all <= 2 && R == 2) continue;
+    const int slices = (nt_all + NT - 1) / NT;
+    const long wgs = (long)(rows_total / (16 * R)) * slices;
+    const long rounds = (wgs + 255) / 256;
+    double eff = (double)wgs / (double)(256 * rounds);  // share of the CUs' time that has work
+    eff *= (double)nt_all / (double)(slices * NT);      // padding tokens are wasted MFMAs
+    if (eff > best_eff + 0.08) {  // clearly better balance beats a bigger tile
+      best_eff = eff;
+      best = PgShape{R, NT, 1, slices};
+    }
   }
-  sh.ks = 1;
-  while (sh.ks * 2 * nm * 64 <= KH_PG_WG_MAX && (long)tiles * sh.slices * nm * sh.ks < 1536 &&
-         kblocks / (sh.ks * 2) >= 2 * ring_blocks)
-    sh.ks *= 2;
-  return sh;
+  // waves per workgroup: 8 (two per SIMD cover each other's operand stalls) when the launch is
+  // at most one workgroup per CU, else 4; every wave keeps at least two weight rings of K
+  const long wgs = (long)(rows_total / (16 * best.R)) * best.slices;
+  const int want_waves = wgs <= 256 ? 8 : 4;
+  while (best.ks * 2 * nm <= want_waves && best.ks * 2 * nm * 64 <= KH_PG_WG_MAX &&
+         kblocks / (best.ks * 2) >= 2 * ring_blocks)
+    best.ks *= 2;
+  return best;
 }
 template <bool Q, int EPI>
 void pg_launch_cfg(const PgShape& sh, int tiles, int wg, hipStream_t s, const KhPgGemmArgs& a) {
@@ -1264,15 +1270,19 @@ void pg_launch_cfg(const PgShape& sh, int tiles, int wg, hipStream_t s, const Kh
     hipLaunchKernelGGL(kern, dim3(tiles, sh.slices), dim3(wg), lds, s, a);
   };
   if (sh.R == 2 && sh.NT == 8) go(k_pg_gemm<Q, 2, 8, EPI>);
-  else if (sh.R == 2) go(k_pg_gemm<Q, 2, 4, EPI>);
+  else if (sh.R == 2 && sh.NT == 4) go(k_pg_gemm<Q, 2, 4, EPI>);
+  else if (sh.R == 2) go(k_pg_gemm<Q, 2, 2, EPI>);
   else go(k_pg_gemm<Q, 1, 4, EPI>);
 }
 template <int EPI>
 void pg_launch(kh_model* m, int rows_total, bool r2_ok, const KhPgGemmArgs& a) {
   const bool q = m->cfg.is_quant;
   const int nm = EPI == KH_PG_SWIGLU ? 2 : 1;
-  PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 2 : 4);
-  if (sh.R == 1 && sh.NT == 8) sh.NT = 4, sh.slices = 2;  // (1, 8) is not instantiated
+  const PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 2 : 4);
+  if (getenv("KH_PG_DEBUG"))
+    fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d (%d wgs x %d waves)\n", EPI,
+            rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, rows_total / (16 * sh.R) * sh.slices,
+            nm * sh.ks);
   const int tiles = rows_total / (16 * sh.R);
   if (q) pg_launch_cfg<true, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a);
   else pg_launch_cfg<false, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a);

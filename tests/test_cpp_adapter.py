@@ -111,6 +111,36 @@ def test_demo_cli_text_prompt_with_sentencepiece_tokenizer(gpu, oracle, tmp_path
     assert tok.decode(want) == spm.SentencePieceProcessor(model_file=tok_path).decode(want)
 
 
+@pytest.mark.gpu
+def test_demo_cli_text_prompt_with_bpe_tokenizer_json(gpu, oracle, tmp_path):
+    """--tokenizer-json/--text: the byte-level BPE layer of the Llama-3 / Qwen2 builds (encode.cpp:59-183):
+    BOS + encode with the reference's space replacement, stop at either stop id, decoded text printed;
+    ids equal the oracle's run on the same prompt ids."""
+    import torch
+    from conftest import GOLDEN
+    from kuiperllama_amd import binfmt
+    from kuiperllama_amd.tokenizer import BpeTokenizer, LLAMA3
+    tok_path = os.path.join(GOLDEN, "bpe_llama3_like.json")
+    tok = BpeTokenizer.from_file(tok_path, LLAMA3)
+    spec = binfmt.ModelSpec(256, 512, 2, 4, 2, tok.vocab_size, 128, True, binfmt.FAMILY_LLAMA, False, 64,
+                            binfmt.ROPE_HALF, 500000.0, 1e-5, "demo-bpe")
+    img = binfmt.synth_image(spec, seed=12, device=torch.device("cpu")).numpy()
+    path = tmp_path / "m.bin"
+    img.tofile(path)
+    text = "Once upon a time there was a little dragon"
+    prompt = tok.encode(text)
+    assert prompt[0] == tok.bos_id and len(prompt) > 3
+    want = oracle.OracleModel.from_spec(img, spec).generate(prompt, 40, stop=tok.stop_ids)
+    exe = build.build_demo()
+    r = subprocess.run([exe, str(path), "--rope", "half", "--theta", "500000", "--steps", "40",
+                        "--tokenizer-json", tok_path, "--text", text],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.split("\n")
+    assert [int(t) for t in lines[2].split()] == want
+    assert lines[1].rstrip(" ") == tok.decode(want).rstrip(" ")
+
+
 def test_demo_cli_builds_and_fails_loudly_without_gpu(tmp_path):
     import torch
     if torch.cuda.is_available():

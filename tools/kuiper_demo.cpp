@@ -1,14 +1,17 @@
 // kuiper_demo — command-line twin of the reference's demo/main.cpp / demo/main_qwen.cpp on top of
 // the C-ABI (include/kuiper_hip.h).  The reference hard-codes tokenizer type, quantisation,
 // device and prompt in the source; here they are flags.  The prompt is given as
-// token ids (--prompt) or, with a SentencePiece-BPE tokenizer.model (--tokenizer, the reference's
-// second argument, main.cpp:56), as text (--text): BOS + encode like SpeEncodeLayer, stop at
-// eos_id, decoded text printed like main.cpp:43-45.
+// token ids (--prompt) or as text (--text) with the tokenizer file the reference takes as its second
+// argument (main.cpp:56): a SentencePiece-BPE tokenizer.model (--tokenizer: BOS + encode like
+// SpeEncodeLayer, stop at eos_id) or a HuggingFace tokenizer.json (--tokenizer-json: the byte-level BPE
+// of the LLAMA3_SUPPORT / QWEN2_SUPPORT builds, encode.cpp:59-183 - BOS for Llama-3 and not for Qwen2,
+// the reference's space -> "Ġ" replacement unless --hf-spaces, two stop ids); the decoded text is
+// printed like main.cpp:43-45.
 //
 //   kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]
 //               [--theta 10000] [--eps 1e-5] [--steps 128] [--prompt 1,263] [--stop 2]
 //               [--exec graph|fused|unfused] [--max-seq-len N] [--device 0]
-//               [--tokenizer tokenizer.model --text "a"]
+//               [--tokenizer tokenizer.model | --tokenizer-json tokenizer.json [--hf-spaces]] [--text "a"]
 //
 // Prints the generated ids and "steps/s" like demo/main.cpp:70-72.
 #include <chrono>
@@ -24,7 +27,8 @@ static void usage() {
   std::fprintf(stderr,
                "usage: kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]\n"
                "       [--theta F] [--eps F] [--steps N] [--prompt id,id,...] [--stop id,id] [--exec graph|fused|unfused]\n"
-               "       [--max-seq-len N] [--device D] [--tokenizer tokenizer.model --text \"...\"]\n");
+               "       [--max-seq-len N] [--device D] [--tokenizer tokenizer.model | --tokenizer-json tokenizer.json\n"
+               "       [--hf-spaces]] [--text \"...\"]\n");
 }
 
 int main(int argc, char** argv) {
@@ -38,6 +42,8 @@ int main(int argc, char** argv) {
   std::vector<int32_t> stop;  // is_sentence_ending ids (main.cpp:30): eos / <|eot_id|> / ...
   std::vector<int32_t> prompt{1, 263};  // BOS + "a": the reference demo's prompt (main.cpp:64)
   const char* tok_path = nullptr;
+  const char* bpe_path = nullptr;
+  int bpe_flags = KH_BPE_REF_SPACES;  // the reference's behaviour (encode.cpp:108-111)
   std::string text;
   bool have_text = false;
   for (int i = 2; i < argc; ++i) {
@@ -56,6 +62,8 @@ int main(int argc, char** argv) {
     else if (a == "--eps") o.rms_eps = (float)std::atof(next());
     else if (a == "--steps") steps = std::atoi(next());
     else if (a == "--tokenizer") tok_path = next();
+    else if (a == "--tokenizer-json") bpe_path = next();
+    else if (a == "--hf-spaces") bpe_flags = 0;
     else if (a == "--text") {
       text = next();
       have_text = true;
@@ -99,8 +107,35 @@ int main(int argc, char** argv) {
       prompt.resize((size_t)n);
     }
     if (stop.empty()) stop.push_back(kh_spm_eos_id(tok));  // is_sentence_ending, encode.cpp:48-51
-  } else if (have_text) {
-    std::fprintf(stderr, "--text needs --tokenizer\n");
+  }
+  kh_bpe* bpe = nullptr;
+  if (bpe_path) {
+    const int flavor = o.family == KH_FAMILY_QWEN2 ? KH_BPE_QWEN2 : KH_BPE_LLAMA3;
+    const int trc = kh_bpe_create_from_file(bpe_path, flavor, &bpe);
+    if (trc != KH_OK) {
+      std::fprintf(stderr, "tokenizer.json load failed: %d (%s) - expected a byte-level BPE tokenizer.json "
+                           "(Llama-3.x / Qwen2.5); SentencePiece models go to --tokenizer\n",
+                   trc, kh_error_string(trc));
+      return 1;
+    }
+    if (have_text) {  // model.cpp:158-165: BOS for Llama, none for Qwen
+      int32_t n = 0;
+      prompt.assign(text.size() * 2 + 8, 0);
+      if (kh_bpe_encode(bpe, text.data(), (int64_t)text.size(), flavor == KH_BPE_LLAMA3, 0, bpe_flags,
+                        prompt.data(), (int32_t)prompt.size(), &n) != KH_OK) {
+        std::fprintf(stderr, "encode failed\n");
+        return 1;
+      }
+      prompt.resize((size_t)n);
+    }
+    if (stop.empty()) {  // is_sentence_ending, encode.cpp:130-136
+      stop.push_back(kh_bpe_stop_id(bpe, 0));
+      stop.push_back(kh_bpe_stop_id(bpe, 1));
+    }
+  }
+  if (have_text && !tok && !bpe) {
+    std::fprintf(stderr, "--text needs --tokenizer (SentencePiece tokenizer.model) or --tokenizer-json "
+                         "(HuggingFace byte-level BPE tokenizer.json)\n");
     return 2;
   }
   kh_model* m = nullptr;
@@ -135,6 +170,13 @@ int main(int argc, char** argv) {
     if (kh_spm_decode(tok, words.data(), n, buf.data(), (int64_t)buf.size(), &len) == KH_OK)
       std::printf("%.*s \n", (int)len, buf.data());
     kh_spm_destroy(tok);
+  }
+  if (bpe) {
+    std::vector<char> buf((size_t)n * 32 + 16);
+    int64_t len = 0;
+    if (kh_bpe_decode(bpe, words.data(), n, bpe_flags, buf.data(), (int64_t)buf.size(), &len) == KH_OK)
+      std::printf("%.*s \n", (int)len, buf.data());
+    kh_bpe_destroy(bpe);
   }
   for (int i = 0; i < n; ++i) std::printf("%d ", words[i]);
   const double dur = std::chrono::duration<double>(t1 - t0).count();
