@@ -171,8 +171,6 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 #define KH_ATTN_MIN_TS 256  // timesteps per split before a second split is opened
 #endif
 #define KH_ATTN_MAX_NS 16
-#define KH_ATTN_PF_BLOCKS 192        // weight-prefetch workgroups riding on the decode launch
-#define KH_ATTN_PF_MAXPOS 2048      // attention is HBM-bound itself beyond this: no prefetch
 #define KH_ATTN_TLONG_DEFAULT 4096  // pos + 1 from which GQA models switch to the group path
 #define KH_ATTN_MAX_NS_G 32          // splits per KV group (the last arriver merges them all)
 #define KH_ATTN_MIN_GROUPS 4         // fewer KV heads than this: too few workgroups, stay per-head
@@ -592,15 +590,6 @@ struct KhAttnArgs {
   // out rows tok_stride floats apart, its split workspace ws_tok_bytes apart (decode: y = 1)
   int tok_stride;
   size_t ws_tok_bytes;
-  // decode only: workgroups pf_block0.. of the grid do no attention; they pull the NEXT kernel's
-  // weights (wo of this layer) through the memory system with plain loads while the attention
-  // workgroups - a latency-bound kernel that leaves HBM idle for ~3.7 us at short contexts - run.
-  // The wo GEMV that follows then finds its 17 MB in the Infinity Cache (measured: a slab read by
-  // a preceding plain-load pass streams ~2.4x faster, profiles/r2_mb_chain.txt Q1).  Skipped from
-  // position pf_maxpos on, where attention itself keeps HBM busy.
-  const char* pf_ptr;
-  size_t pf_bytes;
-  int pf_block0, pf_maxpos;
 };
 
 // per-head path: block -> (kv group g, head-in-group j, split s).  Blocks are placed on XCD
@@ -635,24 +624,6 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(KhAttnArgs a, int hos
     a.ws = (char*)a.ws + (size_t)t * a.ws_tok_bytes;
   }
   const int b = (int)blockIdx.x;
-  if (a.pf_bytes && b >= a.pf_block0) {  // weight prefetch workgroups (uniform per workgroup)
-    if (pos < a.pf_maxpos) {
-      const size_t stride = (size_t)(gridDim.x - a.pf_block0) * blockDim.x * 16;
-      size_t off = ((size_t)(b - a.pf_block0) * blockDim.x + threadIdx.x) * 16;
-      for (; off + 3 * stride + 16 <= a.pf_bytes; off += 4 * stride) {
-        const f32x4 v0 = *(const f32x4*)(a.pf_ptr + off);
-        const f32x4 v1 = *(const f32x4*)(a.pf_ptr + off + stride);
-        const f32x4 v2 = *(const f32x4*)(a.pf_ptr + off + 2 * stride);
-        const f32x4 v3 = *(const f32x4*)(a.pf_ptr + off + 3 * stride);
-        asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));  // keep the loads, use nothing
-      }
-      for (; off + 16 <= a.pf_bytes; off += stride) {
-        const f32x4 v0 = *(const f32x4*)(a.pf_ptr + off);
-        asm volatile("" ::"v"(v0));
-      }
-    }
-    return;
-  }
   if (KVM == 0 || pos + 1 < a.t_long) {
     if (b < a.kv_heads * a.kv_mul * a.nsplit) attn_head_block<G>(a, (float*)smem_raw, b, pos);
     return;
@@ -716,12 +687,6 @@ static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStr
     if (l2 > lds) lds = l2;
   }
   if (grid < 1) grid = 1;
-  if (a.pf_bytes && ntok == 1) {
-    a.pf_block0 = grid;
-    grid += KH_ATTN_PF_BLOCKS;
-  } else {
-    a.pf_bytes = 0;
-  }
 #define KH_ATTN_LAUNCH(GG, KK) \
   hipLaunchKernelGGL((k_attn_decode<GG, KK>), dim3(grid, ntok), dim3(wg), lds, s, a, host_pos)
   const int kvm = grp ? a.kv_mul : 0;

@@ -60,7 +60,6 @@ struct kh_model {
   int attn_ws_stride = 1;   // split slots per head in attn_ws
   int attn_t_long = 1 << 30;
   int attn_wg = KH_WG;
-  bool attn_prefetch = false;  // wo weights pulled into the Infinity Cache beside the attention launch
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
@@ -275,15 +274,6 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   a.t_long = m->attn_t_long;
   a.tok_stride = 0;
   a.ws_tok_bytes = 0;
-  a.pf_ptr = nullptr;
-  a.pf_bytes = 0;
-  a.pf_block0 = 0;
-  a.pf_maxpos = KH_ATTN_PF_MAXPOS;
-  if (m->attn_prefetch) {  // the wo weights (+ scales: contiguous behind them, layer.cpp:209-215)
-    const size_t n = (size_t)c.dim * c.dim;
-    a.pf_ptr = (const char*)m->layers[l].wo.w;
-    a.pf_bytes = c.is_quant ? n + (n / (size_t)c.group_size) * sizeof(float) : n * sizeof(float);
-  }
   return a;
 }
 int attn_group_lanes(const kh_config& c) {
@@ -764,10 +754,6 @@ int finish_create(kh_model* m) {
       if (m->attn_ns_g > m->attn_ws_stride) m->attn_ws_stride = m->attn_ns_g;
     }
   }
-  // (KH_ATTN_PF=0 switches the prefetch off; tiny matrices gain nothing: they sit at the ~3 us
-  // floor of a dependent kernel whatever the memory system does)
-  m->attn_prefetch = c.head_size > 32 && (size_t)c.dim * c.dim * (c.is_quant ? 1 : 4) >= ((size_t)8 << 20);
-  if (const char* e = getenv("KH_ATTN_PF")) m->attn_prefetch = m->attn_prefetch && e[0] != '0';
   if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride)) {
     KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
     KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));
@@ -1181,7 +1167,6 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
       a.ws = m->pf_ws;
       a.tok_stride = c.dim;
       a.ws_tok_bytes = m->pf_ws_tok_bytes;
-      a.pf_bytes = 0;
       launch_attn_decode(a, pos0, m->attn_wg, m->stream, nvalid, pos0 + nvalid - 1);
     }
     pf_gemv_res(m, m->sh_wo, W.wo, m->pf_att, m->pf_x, c.dim, c.dim, nvalid, B);
@@ -1334,7 +1319,6 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       a.ws = m->pg_ws;
       a.tok_stride = c.dim;
       a.ws_tok_bytes = m->pg_ws_tok_bytes;
-      a.pf_bytes = 0;
       launch_attn_decode(a, pos0, m->attn_wg, m->stream, T, pos0 + T - 1);
     }
     {

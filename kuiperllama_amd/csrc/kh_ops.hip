@@ -491,10 +491,6 @@ static int launch_mha_fast(const int32_t* d_pos, int32_t pos, int32_t head_num,
   a.t_long = t_long;
   a.tok_stride = 0;
   a.ws_tok_bytes = 0;
-  a.pf_ptr = nullptr;  // operator-level call: no neighbouring kernel to prefetch for
-  a.pf_bytes = 0;
-  a.pf_block0 = 0;
-  a.pf_maxpos = 0;
   launch_attn_decode(a, pos, KH_WG_MAX, s);
   return kh_launch_status();
 }
