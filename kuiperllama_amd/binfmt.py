@@ -255,7 +255,7 @@ def synth_image(spec: ModelSpec, seed: int = 1234, device: str | torch.device = 
         if e.dtype == "i8":
             std = std_res if base in ("wo", "w3") else 0.02
             n = e.nbytes
-            # quantise in row blocks to bound the fp32 transient (11008x4096 = 180 MB)
+            # one tensor at a time: the fp32 transient is at most 11008x4096x4 = 180 MB
             w = torch.empty(n, dtype=torch.float32, device=device).normal_(0.0, std, generator=gen)
             q, sc = quantize_q80_torch(w, spec.group_size)
             img[e.offset: e.offset + n] = q.view(torch.uint8)

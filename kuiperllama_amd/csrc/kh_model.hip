@@ -1050,31 +1050,35 @@ int ensure_prefill_buffers(kh_model* m) {
 // is clipped to one resident round (the result does not depend on the grid).
 template <class K, class A>
 void pf_launch(K kernel, int grid, int wg, size_t lds, hipStream_t s, const A& args) {
+  // resident-workgroup count and the >64 KiB LDS opt-in are per (device, kernel, shape): a thread
+  // that drives models on several GPUs must not reuse device A's answer (or skip the attribute)
+  // on device B
   struct Cached {
+    int dev;
     const void* fn;
     int wg;
     size_t lds;
     int resident;
   };
   static thread_local std::vector<Cached> cache;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   int resident = 0;
   for (const auto& c : cache)
-    if (c.fn == (const void*)kernel && c.wg == wg && c.lds == lds) resident = c.resident;
+    if (c.dev == dev && c.fn == (const void*)kernel && c.wg == wg && c.lds == lds) resident = c.resident;
   if (!resident) {
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
-    int per_cu = 0, dev = 0, cus = 256;
+    int per_cu = 0, cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, wg, lds) != hipSuccess ||
         per_cu < 1)
       per_cu = 1;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      int v = 0;
-      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-        cus = v;
-    }
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
     resident = per_cu * cus;
-    cache.push_back({(const void*)kernel, wg, lds, resident});
+    cache.push_back({dev, (const void*)kernel, wg, lds, resident});
   }
   if (grid > resident) grid = resident;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(wg), lds, s, args);
@@ -1554,19 +1558,31 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     Chunk infl[2];
     int n_infl = 0, head = 0, launched = start, stop_at = -1;
     for (int i = 0; i < start; ++i) m->h_words_pin[i] = h_prompt[i + 1];
+    // Once chunks are queued, an early return must not leave graph launches and their D2H copies
+    // into h_words_pin in flight (the caller may destroy the model or start another generate that
+    // reallocates those buffers): every error path below drains the stream first.
+    auto fail = [&](int code) -> int {
+      (void)hipStreamSynchronize(m->stream);
+      return code;
+    };
+#define KH_CHECK_DRAIN(expr)                          \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return fail((int)_e);       \
+  } while (0)
     while (stop_at < 0 && (launched < total_steps || n_infl > 0)) {
       while (launched < total_steps && n_infl < 2) {
         const int n = launch_chunk(launched);
-        if (n < 0) return (int)hipErrorUnknown;
+        if (n < 0) return fail((int)hipErrorUnknown);
         const int slot = (head + n_infl) & 1;
-        KH_CHECK_HIP(hipMemcpyAsync(m->h_words_pin + launched, m->d_words + launched,
-                                    sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
-        KH_CHECK_HIP(hipEventRecord(m->ev_chunk[slot], m->stream));
+        KH_CHECK_DRAIN(hipMemcpyAsync(m->h_words_pin + launched, m->d_words + launched,
+                                      sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+        KH_CHECK_DRAIN(hipEventRecord(m->ev_chunk[slot], m->stream));
         infl[slot] = {launched, n};
         launched += n;
         ++n_infl;
       }
-      KH_CHECK_HIP(hipEventSynchronize(m->ev_chunk[head]));
+      KH_CHECK_DRAIN(hipEventSynchronize(m->ev_chunk[head]));
       const Chunk c0 = infl[head];
       for (int s = c0.s0; s < c0.s0 + c0.n; ++s)
         if (s >= n_prompt - 1 && is_stop(m->h_words_pin[s], h_stop, n_stop)) {
@@ -1574,14 +1590,17 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
           break;
         }
       if (stop_at >= 0) {
-        // the loop time the reference would report ends with the step that produced the stop
-        KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));  // (after the queued overshoot)
+        // elapsed_ms ends behind the chunks already queued when the stop token was seen: it
+        // includes up to 2 x 8 discarded steps past the stop (the reference's timer ends with the
+        // step that produced it)
+        KH_CHECK_DRAIN(hipEventRecord(m->ev1, m->stream));
       }
       head ^= 1;
       --n_infl;
     }
-    if (stop_at < 0) KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
-    if ((rc = kh_launch_status()) != KH_OK) return rc;
+    if (stop_at < 0) KH_CHECK_DRAIN(hipEventRecord(m->ev1, m->stream));
+    if ((rc = kh_launch_status()) != KH_OK) return fail(rc);
+#undef KH_CHECK_DRAIN
     KH_CHECK_HIP(hipStreamSynchronize(m->stream));
     n_out = stop_at >= 0 ? stop_at : total_steps;
     memcpy(h_words, m->h_words_pin, sizeof(int32_t) * (size_t)n_out);

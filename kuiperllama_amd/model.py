@@ -57,10 +57,14 @@ class KuiperModel:
     @classmethod
     def from_device_image(cls, image: torch.Tensor, spec: binfmt.ModelSpec, max_seq_len: int = 0,
                           device: int = 0, flags: int = 0) -> "KuiperModel":
-        """image: uint8 GPU tensor with the .bin bytes (header included).  The weights are
-        re-based once so that the data after the header is 256-byte aligned, then used in
-        place (not copied again, not owned by the library)."""
+        """image: uint8 GPU tensor with the .bin bytes (header included), resident on `device`.
+        The library needs the bytes after the 28 / 32-byte header at a 16-byte aligned address:
+        they are used in place when they already are, otherwise copied once into an aligned
+        tensor (which transiently doubles the weight memory).  Not owned by the library."""
         assert image.is_cuda and image.dtype == torch.uint8
+        if image.device.index != device:
+            raise ValueError(f"image lives on cuda:{image.device.index} but the model is created on "
+                             f"device {device}: kernels would dereference another GPU's pointers")
         hb = spec.header_bytes()
         header = np.frombuffer(image[:32].cpu().numpy().tobytes(), dtype=np.int32).copy()
         if (image.data_ptr() + hb) % 16 == 0:
@@ -135,8 +139,9 @@ class KuiperModel:
         return list(words[: n.value]), float(ms.value)
 
     def prefill(self, tokens: Sequence[int], pos0: int = 0) -> None:
-        """Forward of `tokens` at positions pos0.. without logits, 4 tokens per weight pass; the
-        K/V rows are bit-identical to token-by-token predict(is_prompt=True)."""
+        """Forward of `tokens` at positions pos0.. without logits, 8 (fp32) / 4 (int8) tokens per
+        weight pass on the VALU; the K/V rows are bit-identical to token-by-token
+        predict(is_prompt=True)."""
         t = (C.c_int32 * len(tokens))(*[int(x) for x in tokens])
         _ffi.check(_ffi.lib().kh_model_prefill(self._h, t, len(tokens), pos0), "kh_model_prefill")
         torch.cuda.synchronize()
