@@ -62,6 +62,15 @@ def embedding(tokens, w, out):
     return out
 
 
+def embedding_host_tokens(tokens, w, out):
+    """EmbeddingKernel as the reference calls it: `tokens` is a HOST int32 array (numpy); the ids
+    travel in the kernel arguments, 64 per launch (kh_embedding_f32_host)."""
+    import numpy as np
+    t = np.ascontiguousarray(tokens, dtype=np.int32)
+    _ffi.check(_ffi.lib().kh_embedding_f32_host(t.ctypes.data, t.size, _p(w), _p(out), w.shape[1],
+                                                w.shape[0], _stream()), "kh_embedding_f32_host")
+
+
 def swiglu(a, b, out):
     _ffi.check(_ffi.lib().kh_swiglu_f32(_p(a, torch.float32), _p(b, torch.float32),
                                         _p(out, torch.float32), a.numel(), _stream()),

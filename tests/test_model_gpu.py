@@ -539,3 +539,45 @@ def test_gemm_prefill_full_size(gpu, oracle, preset):
             assert e_pair <= (2e-5 if li == 0 else 2e-4), (layers[li], e_pair)
     np.testing.assert_allclose(la, lo, rtol=0, atol=_atol(spec) * 2)
     assert na == int(np.argmax(lo))
+
+
+def test_prefill_api_modes_and_errors(gpu):
+    """kh_model_time_prefill: the three prompt phases leave the same cache rows (token == gemv bit
+    for bit, gemm to fp32 round-off) and report a duration; argument errors come back as codes."""
+    from kuiperllama_amd import _ffi
+    from kuiperllama_amd.model import KuiperModel
+    spec = _PF_SPECS["gqa-half"]
+    img_d, _ = _synth(spec, 77, gpu)
+    rng = np.random.default_rng(2)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, 40)]
+    kv = {}
+    for mode in ("token", "gemv", "gemm"):
+        m = KuiperModel.from_device_image(img_d, spec)
+        ms = m.time_prefill(toks, 0, mode)
+        assert ms > 0
+        kv[mode] = [m.read_kv(l, 0, len(toks)) for l in range(spec.n_layers)]
+        m.close()
+    for l in range(spec.n_layers):
+        assert np.array_equal(kv["token"][l][0], kv["gemv"][l][0])
+        assert np.array_equal(kv["token"][l][1], kv["gemv"][l][1])
+        np.testing.assert_allclose(kv["gemm"][l][0], kv["token"][l][0], rtol=0, atol=KV_ATOL_GEMM)
+        np.testing.assert_allclose(kv["gemm"][l][1], kv["token"][l][1], rtol=0, atol=KV_ATOL_GEMM)
+    m = KuiperModel.from_device_image(img_d, spec)
+    with pytest.raises(_ffi.KhError) as ei:
+        m.prefill_gemm([1, 2, 3], spec.seq_len - 1)  # runs past the cache
+    assert ei.value.code == -6
+    with pytest.raises(_ffi.KhError) as ei:
+        m.prefill_gemm([spec.vocab_size], 0)
+    assert ei.value.code == -6
+    with pytest.raises(_ffi.KhError) as ei:
+        m.prefill_gemm([], 0)
+    assert ei.value.code == -1
+    m.close()
+    # head_size 32 (tiny golden model): no multi-token attention kernel -> unsupported, stated as such
+    s2, img, _, _ = load_golden("ref_llama_gqa_tied")
+    if s2.head_size <= 32:
+        m2 = KuiperModel.from_host_image(img, s2)
+        with pytest.raises(_ffi.KhError) as ei:
+            m2.prefill_gemm([1, 2, 3, 4], 0)
+        assert ei.value.code == -2
+        m2.close()

@@ -168,6 +168,29 @@ def test_embedding_reference_case(gpu, oracle):
     assert np.all(h[0] == 7.0) and np.array_equal(h[1], w[3])
 
 
+def test_embedding_host_tokens_equals_device_tokens(gpu):
+    """kh_embedding_f32_host (ids in the kernel arguments, 64 per launch - what the adapter hands the
+    reference's HOST token tensor to) == kh_embedding_f32 with a device token array: 1, 64, 65 and
+    700 tokens, out-of-vocabulary ids leave their rows untouched (emb_kernel.cu:10-12)."""
+    from kuiperllama_amd import ops
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((211, 72)).astype(np.float32)
+    wd = dev(w, gpu)
+    for n in (1, 64, 65, 700):
+        toks = rng.integers(0, 211, n).astype(np.int32)
+        toks[n // 2] = 211 + n  # one id outside the vocabulary
+        a = torch.full((n, 72), -3.0, device=gpu)
+        b = torch.full((n, 72), -3.0, device=gpu)
+        ops.embedding(dev(toks, gpu), wd, a)
+        ops.embedding_host_tokens(toks, wd, b)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(a), host(b)), n
+        assert np.all(host(b)[n // 2] == -3.0)
+        ok = np.ones(n, bool)
+        ok[n // 2] = False
+        assert np.array_equal(host(b)[ok], w[toks[ok]])
+
+
 @pytest.mark.parametrize("n", [1, 5, 1024, 32000, 128256, 151936])
 def test_argmax_first_maximum(gpu, oracle, n):
     from kuiperllama_amd import ops
