@@ -156,7 +156,8 @@ def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=1
     div = next((i for i in range(n_cmp) if words[i] != gpu_words[i]), None)
     match = n_cmp > 0 and div is None
     how = ("fp32 matmuls via numpy's bundled OpenBLAS sgemv (the reference's Armadillo->BLAS path)"
-           if variant == "openblas" else "OpenMP row-parallel fp32 GEMV")
+           if variant == "openblas" else
+           ("OpenMP row-parallel int8 group-dequant GEMV" if spec.quant else "OpenMP row-parallel fp32 GEMV"))
     return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"{n} decode steps = {passes} pass(es) over the first {len(words)} steps of the "
                       f"same greedy decode ({spec.name}, prompt {PROMPT}), {how}, {dt:.1f}s",
