@@ -1229,40 +1229,53 @@ int ensure_pg_buffers(kh_model* m) {
   return KH_OK;
 }
 // Launch shape of one prefill GEMM (kh_gemm.h): R 16-row tiles and NT 16-token tiles per wave,
-// ks waves splitting K per workgroup, grid.y token slices.  A workgroup lives on ONE CU, so what
-// matters first is that the launch has a whole number of workgroups per CU (a 128-workgroup launch
-// of 8-wave groups leaves half the chip idle: measured on the 1B wo / w2 GEMMs); among the shapes
-// that fill the chip equally well the largest register tile wins (fewest operand bytes per MFMA).
+// ks waves splitting K per workgroup, grid.y token slices.  Picked by a small cost model of the
+// busiest SIMD, fitted to a sweep on Llama-3.2-1B (profiles/r2_gemm_shape_sweep.txt):
+//   * a workgroup lives on ONE CU: fewer than 256 workgroups leave CUs idle (the model prices the
+//     busiest CU, so such shapes simply show their long per-wave work);
+//   * fp32: ONE wave per SIMD is the sweet spot: two MFMA-bound waves on a SIMD cost ~1.6x the
+//     time of the same work in one wave (the (w1,w3) GEMM went 140 -> 84 us per launch from 8 to 4
+//     waves per CU), three or more ~1.8x;  int8: the opposite - its waves spend VALU time on the
+//     dequant between MFMAs, so a second and third wave per SIMD fill the matrix pipe
+//     (profiles/r2_gemm_shape_sweep_7b.txt: (w1,w3) 2 -> 4 waves per workgroup 30.4 -> 23.3 ms per
+//     prefill), up to what the register file admits;
+//   * bigger register tiles need fewer operand bytes per MFMA (small factor), more token slices
+//     re-read the weights from L2 (small factor), padding tokens are wasted MFMAs.
 struct PgShape {
   int R, NT, ks, slices;
 };
-PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int ring_blocks) {
+PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int ring_blocks, bool quant) {
   const int nt_all = (T + 15) / 16;
-  static const int cand[4][2] = {{2, 8}, {2, 4}, {2, 2}, {1, 4}};
+  static const int cand[4][3] = {{2, 8, 2}, {2, 4, 3}, {2, 2, 4}, {1, 4, 4}};  // R, NT, waves/SIMD that fit
   PgShape best{1, 4, 1, (nt_all + 3) / 4};
-  double best_eff = -1.0;
+  double best_cost = -1.0;
   for (const auto& c : cand) {
-    const int R = c[0], NT = c[1];
+    const int R = c[0], NT = c[1], occ = c[2];
     if (R == 2 && !r2_ok) continue;
-    if (NT > 4 && nt_all <= 4) continue;  // no point in a 128-token tile for <= 64 tokens
-    if (NT > 2 && nt_all <= 2 && R == 2) continue;
+    if (R == 1 && quant && r2_ok) continue;  // int8: the 32-row tile measured better wherever it fits
+    if (NT > 4 && nt_all <= 4) continue;     // no 128-token tile for <= 64 tokens
     const int slices = (nt_all + NT - 1) / NT;
     const long wgs = (long)(rows_total / (16 * R)) * slices;
-    const long rounds = (wgs + 255) / 256;
-    double eff = (double)wgs / (double)(256 * rounds);  // share of the CUs' time that has work
-    eff *= (double)nt_all / (double)(slices * NT);      // padding tokens are wasted MFMAs
-    if (eff > best_eff + 0.08) {  // clearly better balance beats a bigger tile
-      best_eff = eff;
-      best = PgShape{R, NT, 1, slices};
+    for (int ks = 1; ks * nm * 64 <= KH_PG_WG_MAX; ks *= 2) {
+      if (ks > 1 && kblocks / ks < 2 * ring_blocks) break;  // at least two weight rings per wave
+      const long cu_waves = ((wgs + 255) / 256) * (long)(nm * ks);  // on the busiest CU
+      long wps = (cu_waves + 3) / 4;                                // waves per SIMD there
+      const long rounds = (wps + occ - 1) / occ;                    // beyond the register file: queued
+      if (wps > occ) wps = occ;
+      const double pen = quant ? (wps <= 1 ? 1.0 : (wps == 2 ? 0.72 : 0.62))
+                               : (wps <= 1 ? 1.0 : (wps == 2 ? 1.6 : 1.8));
+      const double per_wave = (double)((kblocks + ks - 1) / ks) * R * NT;
+      double cost = per_wave * (double)(wps * rounds) * pen;
+      cost *= 1.0 + 0.15 * (double)(R + NT) / (double)(R * NT);
+      // every token slice re-reads the weights from L2 - and, int8, dequantises them again
+      cost *= 1.0 + (quant ? 0.15 : 0.05) * (double)(slices - 1);
+      cost *= (double)(slices * NT) / (double)nt_all;
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        best = PgShape{R, NT, ks, slices};
+      }
     }
   }
-  // waves per workgroup: 8 (two per SIMD cover each other's operand stalls) when the launch is
-  // at most one workgroup per CU, else 4; every wave keeps at least two weight rings of K
-  const long wgs = (long)(rows_total / (16 * best.R)) * best.slices;
-  const int want_waves = wgs <= 256 ? 8 : 4;
-  while (best.ks * 2 * nm <= want_waves && best.ks * 2 * nm * 64 <= KH_PG_WG_MAX &&
-         kblocks / (best.ks * 2) >= 2 * ring_blocks)
-    best.ks *= 2;
   return best;
 }
 template <bool Q, int EPI>
@@ -1282,7 +1295,16 @@ template <int EPI>
 void pg_launch(kh_model* m, int rows_total, bool r2_ok, const KhPgGemmArgs& a) {
   const bool q = m->cfg.is_quant;
   const int nm = EPI == KH_PG_SWIGLU ? 2 : 1;
-  const PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 2 : 4);
+  PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 2 : 4, q);
+  {  // tuning hook: KH_PG_SHAPE_<QKV|RESID|SWIGLU>="R,NT,ks" overrides the heuristic
+    static const char* const names[3] = {"KH_PG_SHAPE_QKV", "KH_PG_SHAPE_RESID", "KH_PG_SHAPE_SWIGLU"};
+    if (const char* ov = getenv(names[EPI])) {
+      int R = 0, NT = 0, ks = 0;
+      if (sscanf(ov, "%d,%d,%d", &R, &NT, &ks) == 3 && ((R == 2 && (NT == 2 || NT == 4 || NT == 8) && r2_ok) || (R == 1 && NT == 4)) &&
+          (ks == 1 || ks == 2 || ks == 4 || ks == 8) && ks * nm * 64 <= KH_PG_WG_MAX)
+        sh = PgShape{R, NT, ks, ((a.T + 15) / 16 + NT - 1) / NT};
+    }
+  }
   if (getenv("KH_PG_DEBUG"))
     fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d (%d wgs x %d waves)\n", EPI,
             rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, rows_total / (16 * sh.R) * sh.slices,
