@@ -50,7 +50,11 @@
 #ifndef KH_PG_EXP_NOB
 #define KH_PG_EXP_NOB 0          // activation operand loaded once per wave instead of streamed
 #endif
-#define KH_PG_WG_MAX 512         // <= 8 waves per workgroup: 256 VGPRs per lane stay available
+// Workgroup width: <= 8 waves.  The fp32 shapes use 4 (ONE wave per SIMD, see pg_shape); int8 up to 8
+// (its dequant VALU work wants a partner wave on the SIMD to keep the matrix pipe busy).
+#define KH_PG_WG_MAX_F32 512
+#define KH_PG_WG_MAX_Q8 512
+#define KH_PG_WG_MAX(QUANT) ((QUANT) ? KH_PG_WG_MAX_Q8 : KH_PG_WG_MAX_F32)
 
 enum { KH_PG_QKV = 0, KH_PG_RESID = 1, KH_PG_SWIGLU = 2 };
 
@@ -133,7 +137,10 @@ struct PgBAddr {           // activation operand addressing: base + nt*s_nt + bl
 template <int R, int NT>
 __device__ __forceinline__ void pg_kloop_f32(const float* const (&wrow)[R], const PgBAddr& B, int b0,
                                              int b1, f32x4 (&acc)[R][NT]) {
-  constexpr int RING = (R == 2 && NT >= 4) ? 4 : 8;  // blocks per weight ring (register budget)
+  // blocks per weight ring (two rings per wave).  Deeper rings were tried for the one-wave-per-SIMD
+  // shapes - 2 x 32 / 16 blocks (the excess lands in AGPRs: 4.04 ms per 128-token prefill) and
+  // 2 x 16 / 8 within the 256 architectural VGPRs (3.76 ms) - against 3.71 ms with these.
+  constexpr int RING = (R == 2 && NT >= 4) ? 4 : 8;
   f32x4 a[2][RING][R];
   f32x4 xb[2][NT];
   const int last = b1 - 1;
@@ -227,7 +234,7 @@ __device__ __forceinline__ void pg_kloop_q8(const int8_t* const (&wrow)[R],
 // blockDim.x = NM * ks * 64 (NM = 2 for SWIGLU); blockIdx.x = (16*R)-row tile; blockIdx.y = slice of
 // 16*NT tokens.  LDS: [waves][NT][64] float4 partial tiles (skipped when one wave owns the whole K).
 template <bool QUANT, int R, int NT, int EPI>
-__global__ __launch_bounds__(KH_PG_WG_MAX) void k_pg_gemm(const KhPgGemmArgs a) {
+__global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int NM = EPI == KH_PG_SWIGLU ? 2 : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

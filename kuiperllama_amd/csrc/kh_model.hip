@@ -1244,7 +1244,7 @@ int ensure_pg_buffers(kh_model* m) {
 struct PgShape {
   int R, NT, ks, slices;
 };
-PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int ring_blocks, bool quant) {
+PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min_blocks, bool quant) {
   const int nt_all = (T + 15) / 16;
   static const int cand[4][3] = {{2, 8, 2}, {2, 4, 3}, {2, 2, 4}, {1, 4, 4}};  // R, NT, waves/SIMD that fit
   PgShape best{1, 4, 1, (nt_all + 3) / 4};
@@ -1256,8 +1256,8 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int rin
     if (NT > 4 && nt_all <= 4) continue;     // no 128-token tile for <= 64 tokens
     const int slices = (nt_all + NT - 1) / NT;
     const long wgs = (long)(rows_total / (16 * R)) * slices;
-    for (int ks = 1; ks * nm * 64 <= KH_PG_WG_MAX; ks *= 2) {
-      if (ks > 1 && kblocks / ks < 2 * ring_blocks) break;  // at least two weight rings per wave
+    for (int ks = 1; ks * nm * 64 <= KH_PG_WG_MAX(quant); ks *= 2) {
+      if (ks > 1 && kblocks / ks < min_blocks) break;  // keep a useful K range per wave
       const long cu_waves = ((wgs + 255) / 256) * (long)(nm * ks);  // on the busiest CU
       long wps = (cu_waves + 3) / 4;                                // waves per SIMD there
       const long rounds = (wps + occ - 1) / occ;                    // beyond the register file: queued
@@ -1295,13 +1295,13 @@ template <int EPI>
 void pg_launch(kh_model* m, int rows_total, bool r2_ok, const KhPgGemmArgs& a) {
   const bool q = m->cfg.is_quant;
   const int nm = EPI == KH_PG_SWIGLU ? 2 : 1;
-  PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 2 : 4, q);
+  PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 4 : 16, q);
   {  // tuning hook: KH_PG_SHAPE_<QKV|RESID|SWIGLU>="R,NT,ks" overrides the heuristic
     static const char* const names[3] = {"KH_PG_SHAPE_QKV", "KH_PG_SHAPE_RESID", "KH_PG_SHAPE_SWIGLU"};
     if (const char* ov = getenv(names[EPI])) {
       int R = 0, NT = 0, ks = 0;
       if (sscanf(ov, "%d,%d,%d", &R, &NT, &ks) == 3 && ((R == 2 && (NT == 2 || NT == 4 || NT == 8) && r2_ok) || (R == 1 && NT == 4)) &&
-          (ks == 1 || ks == 2 || ks == 4 || ks == 8) && ks * nm * 64 <= KH_PG_WG_MAX)
+          (ks == 1 || ks == 2 || ks == 4 || ks == 8) && ks * nm * 64 <= KH_PG_WG_MAX(q))
         sh = PgShape{R, NT, ks, ((a.T + 15) / 16 + NT - 1) / NT};
     }
   }
@@ -1345,7 +1345,10 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       a.ws = m->pg_ws;
       a.tok_stride = c.dim;
       a.ws_tok_bytes = m->pg_ws_tok_bytes;
-      launch_attn_decode(a, pos0, m->attn_wg, m->stream, T, pos0 + T - 1);
+      // 256-thread workgroups: 4096 (head, token) workgroups are latency-bound one-round-trip
+      // kernels; twice as many fit a CU (28.7 -> 19.6 us per layer).  The bit-identical B-token
+      // path keeps the decode width (its summation order depends on it).
+      launch_attn_decode(a, pos0, KH_WG, m->stream, T, pos0 + T - 1);
     }
     {
       KhPgGemmArgs a{};
