@@ -109,6 +109,18 @@ int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num, int32_t laye
                float* mha_out, const float* q, float* score, const float* kcache,
                const float* vcache, void* stream);
 
+/* Multi-token form of MHAKernel for the prompt phase (no reference counterpart: demo/main.cpp:20-22
+ * feeds the prompt one token per forward pass, so mha.cpp:19-38 only ever sees one query).  Causal
+ * attention of n_tokens consecutive queries at positions pos0 .. pos0+n_tokens-1 against one layer's
+ * contiguous cache, whose rows up to pos0+n_tokens-1 are already written; q and mha_out are
+ * row-major [n_tokens][head_num*head_size].  Both contractions (q.K^T, P.V) run on
+ * v_mfma_f32_16x16x4_f32 with an online softmax; per token the result equals kh_mha_f32 at
+ * pos = pos0 + t within the fp32 tolerance.  head_size 48, 64 or 128, else KH_ERR_UNSUPPORTED. */
+int kh_mha_prefill_f32(int32_t pos0, int32_t n_tokens, int32_t head_num, int32_t layer_index,
+                       int32_t seq_len, int32_t kv_dim, int32_t kv_mul, int32_t head_size,
+                       float* mha_out, const float* q, const float* key_cache,
+                       const float* value_cache, void* stream);
+
 /* The decode-path attention kernel with its long-context machinery.  Per-head path: the grid
  * carries ceil(seq_len/256) (<= 16) workgroups per head; positions < 256 use one of them, longer
  * contexts split the timesteps and the last workgroup to finish merges the partial

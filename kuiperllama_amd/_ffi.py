@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("KH_LIB") or os.path.join(_PKG, "lib", "libkuiper_hip.
 EXPORTS = [
     "kh_error_string", "kh_version", "kh_device_count",
     "kh_add_f32", "kh_matmul_f32", "kh_matmul_q8", "kh_embedding_f32", "kh_embedding_f32_host", "kh_swiglu_f32",
-    "kh_rmsnorm_f32", "kh_rope_f32", "kh_sincos_cache_f32", "kh_mha_f32", "kh_mha_decode_f32",
+    "kh_rmsnorm_f32", "kh_rope_f32", "kh_sincos_cache_f32", "kh_mha_f32", "kh_mha_decode_f32", "kh_mha_prefill_f32",
     "kh_mha_decode_workspace_bytes", "kh_argmax_f32",
     "kh_argmax_f32_host", "kh_softmax_f32", "kh_scale_f32", "kh_scale_sum_f32",
     "kh_model_create_from_file", "kh_model_create_from_host_image",
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
                              _vp, _vp]
     L.kh_mha_decode_workspace_bytes.argtypes = [_i32, _i32, _i32]
     L.kh_mha_decode_workspace_bytes.restype = _i64
+    L.kh_mha_prefill_f32.argtypes = [_i32] * 8 + [_vp, _vp, _vp, _vp, _vp]
     L.kh_mha_decode_f32.argtypes = [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _vp]
     L.kh_argmax_f32.argtypes = [_vp, _i64, _vp, _vp]

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "kh_gemm.h"
+#include "kh_pattn.h"
 #include "kh_prefill.h"
 
 namespace {
@@ -1322,6 +1323,9 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
     if (q) hipLaunchKernelGGL(k_pg_rmsnorm<true>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps);
     else hipLaunchKernelGGL(k_pg_rmsnorm<false>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps);
   };
+  // attention of the slice: MFMA kernel (kh_pattn.h) unless KH_PG_ATTN=0 or an odd head size
+  static const bool attn_env = [] { const char* e = getenv("KH_PG_ATTN"); return !(e && e[0] == '0'); }();
+  const bool mfma_attn = attn_env && pg_attn_supported(c.head_size);
   for (int l = 0; l < c.layer_num; ++l) {
     const LayerW& W = m->layers[l];
     float* kc = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
@@ -1337,7 +1341,13 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
     }
     hipLaunchKernelGGL(k_pg_rope, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_q, kc, m->sin_cache,
                        m->cos_cache, c.dim, c.kv_dim, c.head_size, pos0, c.rope_mode);
-    {
+    if (mfma_attn) {
+      KhPgAttnArgs a{};
+      a.q = m->pg_q; a.kc = kc; a.vc = vc; a.out = m->pg_att;
+      a.dim = c.dim; a.kv_dim = c.kv_dim; a.kv_heads = c.kv_head_num; a.kv_mul = c.kv_mul;
+      a.T = T; a.pos0 = pos0; a.layout = q ? KH_PA_TILED_Q8 : KH_PA_TILED_F32;
+      launch_pg_attn(a, c.head_size, m->stream);
+    } else {
       KhAttnArgs a = fill_attn(m, l);
       a.q = m->pg_q;
       a.out = m->pg_att;
@@ -1345,15 +1355,15 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       a.ws = m->pg_ws;
       a.tok_stride = c.dim;
       a.ws_tok_bytes = m->pg_ws_tok_bytes;
-      // 256-thread workgroups: 4096 (head, token) workgroups are latency-bound one-round-trip
-      // kernels; twice as many fit a CU (28.7 -> 19.6 us per layer).  The bit-identical B-token
-      // path keeps the decode width (its summation order depends on it).
+      // head sizes without an MFMA instantiation (and KH_PG_ATTN=0): the decode kernel, one grid
+      // slice per token, 256-thread workgroups (4096 latency-bound (head, token) workgroups: twice
+      // as many fit a CU as with the decode width, 28.7 -> 19.6 us per layer)
       launch_attn_decode(a, pos0, KH_WG, m->stream, T, pos0 + T - 1);
     }
     {
       KhPgGemmArgs a{};
       a.w[0] = W.wo;
-      a.B = m->pg_att; a.b_tiled = 0; a.out = m->pg_x;  // the attention kernel writes row-major rows
+      a.B = m->pg_att; a.b_tiled = mfma_attn ? 1 : 0; a.out = m->pg_x;  // decode kernel: row-major rows
       a.rows0 = c.dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
       pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
     }
@@ -1388,6 +1398,29 @@ extern "C" int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32
   if ((rc = ensure_pg_buffers(m)) != KH_OK) return rc;
   for (int t0 = 0; t0 < n; t0 += KH_PG_TMAX)
     launch_prefill_gemm_chunk(m, h_tokens + t0, n - t0 < KH_PG_TMAX ? n - t0 : KH_PG_TMAX, pos0 + t0);
+  return kh_launch_status();
+}
+
+// Operator-level entry of the MFMA slice attention (kh_pattn.h): the multi-token form of MHAKernel.
+extern "C" int kh_mha_prefill_f32(int32_t pos0, int32_t n_tokens, int32_t head_num, int32_t layer_index,
+                                  int32_t seq_len, int32_t kv_dim, int32_t kv_mul, int32_t head_size,
+                                  float* mha_out, const float* q, const float* key_cache,
+                                  const float* value_cache, void* stream) {
+  if (!mha_out || !q || !key_cache || !value_cache) return KH_ERR_INVALID_ARG;
+  if (n_tokens <= 0 || pos0 < 0 || head_num <= 0 || layer_index < 0 || seq_len <= 0 || kv_mul <= 0 ||
+      head_size <= 0 || kv_dim <= 0)
+    return KH_ERR_INVALID_ARG;
+  if (head_num % kv_mul || kv_dim != (head_num / kv_mul) * head_size) return KH_ERR_INVALID_ARG;
+  if ((int64_t)pos0 + n_tokens > seq_len) return KH_ERR_RANGE;
+  if (!pg_attn_supported(head_size)) return KH_ERR_UNSUPPORTED;
+  if (((uintptr_t)mha_out | (uintptr_t)q | (uintptr_t)key_cache | (uintptr_t)value_cache) & 15)
+    return KH_ERR_INVALID_ARG;  // 16-byte loads / stores
+  KhPgAttnArgs a{};
+  const size_t layer_off = (size_t)layer_index * seq_len * kv_dim;
+  a.q = q; a.kc = key_cache + layer_off; a.vc = value_cache + layer_off; a.out = mha_out;
+  a.dim = head_num * head_size; a.kv_dim = kv_dim; a.kv_heads = head_num / kv_mul; a.kv_mul = kv_mul;
+  a.T = n_tokens; a.pos0 = pos0; a.layout = KH_PA_ROWS;
+  launch_pg_attn(a, head_size, (hipStream_t)stream);
   return kh_launch_status();
 }
 

@@ -1,0 +1,213 @@
+// kh_pattn.h — causal attention of a prompt slice on the matrix cores (GEMM prefill).
+//
+// The reference computes attention one query token at a time (cpu/mha_kernel.cpp:5-61,
+// cuda/mha_kernel.cu:47-110: score = q.k * 1/sqrt(hs), softmax over 0..pos, out = sum p_t v_t).
+// With T prompt tokens in flight, q.K^T and P.V are real GEMMs: here one workgroup owns (head h,
+// 16 query tokens) and its four waves split the key/value timesteps in 16-position tiles; both
+// contractions run on v_mfma_f32_16x16x4_f32 (exact fp32 fmaf chains), the softmax is the online
+// form the decode kernel already uses (running max m, running sum l, rescale by exp(m - m')).
+//
+// The transposed products make the operands fall out of the registers without any shuffle:
+//   S^T[pos, tok] = K[pos, :] . Q[tok, :]      A = K rows (lane i = l&15 -> position), B = Q rows
+//       D layout: lane holds column tok = l&15, rows pos = 4*(l>>4) + reg            (reg 0..3)
+//   O^T[d, tok]  += V^T[d, pos] . P^T[pos, tok]
+//       MFMA #s contracts the position quad {s, 4+s, 8+s, 12+s}: its B operand for k = l>>4 is the
+//       lane's OWN register s of P^T - the D layout of the first product IS the B layout of the
+//       second.  A = V[pos = 4*(l>>4)+s][d]: the lane loads a float4 V[pos][64c + 4i .. +4] and feeds
+//       component a to the accumulator tile (c, a), whose row i stands for d = 64c + 4i + a; in the
+//       D layout a lane then holds d = 64c + 16*(l>>4) + 4*reg + a, i.e. 16 consecutive outputs of
+//       its token - four float4 stores.
+// As in kh_gemm.h the K-side contraction visits the head dimension in the order of the lanes'
+// float4 loads (k-quad {16b+s, 16b+4+s, ...}); any order is a valid dot product.
+//
+// Row statistics: a token's scores sit in 4 registers x 4 lane groups (l>>4); the tile maximum is
+// combined across the groups with two ds_bpermute, so every lane of a token uses the same m and
+// the P values fed to the matrix core are consistently scaled.  The row sum is kept per lane and
+// combined once at the end.  The four waves' (m, l, O) partials merge through LDS in fixed order.
+//
+// Output goes straight into the tiled activation slab the wo GEMM reads (pg_tiled_index).
+#pragma once
+#include "kh_gemm.h"
+
+struct KhPgAttnArgs {
+  const float* q;   // [T][dim] row-major, RoPE applied
+  const float* kc;  // this layer's K cache rows [cache_len][kv_dim]; rows pos0 .. pos0+T-1 just written
+  const float* vc;
+  float* out;       // layout 0 / 1: tiled slab [dim x KH_PG_TMAX] of an fp32 / int8 model
+                    // (pg_tiled_index, T <= KH_PG_TMAX); layout 2: row-major [T][dim]
+  int dim, kv_dim, kv_heads, kv_mul, T, pos0, layout;
+};
+enum { KH_PA_TILED_F32 = 0, KH_PA_TILED_Q8 = 1, KH_PA_ROWS = 2 };
+
+template <int HB /* head_size / 16 */>
+__global__ __launch_bounds__(256) void k_pg_attn(const KhPgAttnArgs a) {
+  constexpr int HS = 16 * HB;
+  constexpr int NC = (HS + 63) / 64;  // 64-wide chunks of the head dimension on the P.V side
+  constexpr int LDO = HS + 4;         // LDS row stride (floats): float4 rows of 16 tokens hit distinct banks
+  __shared__ __attribute__((aligned(16))) float o_lds[4][16][LDO];
+  __shared__ float m_lds[4][16], l_lds[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lj = lane >> 4;
+  // workgroup -> (kv group g, head-in-group j, token tile tt); b % 8 is the XCD: the kv_mul heads
+  // (and all token tiles) that share K/V rows share an XCD's L2.  Long tiles are dispatched first.
+  const int b = (int)blockIdx.x;
+  const int g = b % a.kv_heads;
+  const int rest = b / a.kv_heads;
+  const int j = rest % a.kv_mul;
+  const int n_tt = (a.T + 15) >> 4;
+  const int tt = n_tt - 1 - rest / a.kv_mul;
+  const int h = g * a.kv_mul + j;
+  const int t0 = tt * 16;
+  const int t_last = t0 + 15 < a.T - 1 ? t0 + 15 : a.T - 1;
+  const int p_last = a.pos0 + t_last;  // last timestep any token of this tile attends to
+  const int n_pt = (p_last >> 4) + 1;  // 16-position tiles, aligned at timestep 0
+  const float scale = 1.0f / sqrtf((float)HS);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const int tq = t0 + li < a.T ? t0 + li : a.T - 1;  // this lane's query token (column of both
+                                                     // products); padding columns repeat the last
+  const int my_pos = a.pos0 + tq;                    // it attends to timesteps <= my_pos
+  const float* kbase = a.kc + (size_t)g * HS + 4 * lj;
+  const float* vbase = a.vc + (size_t)g * HS + 4 * li;
+  auto load_k = [&](f32x4(&kf)[HB], int pt) __attribute__((always_inline)) {
+    int p = pt * 16 + li;
+    p = p < p_last ? p : p_last;  // rows past the slice are not written yet: clamp, masked below
+    const float* r = kbase + (size_t)p * a.kv_dim;
+#pragma unroll
+    for (int bb = 0; bb < HB; ++bb) kf[bb] = *(const f32x4*)(r + 16 * bb);
+  };
+  auto load_v = [&](f32x4(&vf)[NC][4], int pt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int p = pt * 16 + lj * 4 + s;
+      p = p < p_last ? p : p_last;
+      const float* r = vbase + (size_t)p * a.kv_dim;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        vf[c][s] = (64 * c + 4 * li < HS) ? *(const f32x4*)(r + 64 * c) : zero4;
+    }
+  };
+
+  f32x4 kf[2][HB], vf[2][NC][4];
+  if (wave < n_pt) {  // wave-uniform
+    load_k(kf[0], wave);
+    load_v(vf[0], wave);
+  }
+  f32x4 qf[HB];
+  {
+    const float* qrow = a.q + (size_t)tq * a.dim + (size_t)h * HS + 4 * lj;
+#pragma unroll
+    for (int bb = 0; bb < HB; ++bb) qf[bb] = *(const f32x4*)(qrow + 16 * bb);
+  }
+  float m = -INFINITY, l = 0.f;
+  f32x4 oacc[NC][4];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oacc[c][e] = zero4;
+
+  auto tile = [&](const f32x4(&kc_)[HB], const f32x4(&vc_)[NC][4], int pt) __attribute__((always_inline)) {
+    f32x4 sacc = zero4;
+#pragma unroll
+    for (int bb = 0; bb < HB; ++bb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sacc = mfma16(pg_comp(kc_[bb], s), pg_comp(qf[bb], s), sacc);
+    const int pb = pt * 16 + lj * 4;
+    float sv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sv[r] = (pb + r <= my_pos) ? pg_comp(sacc, r) * scale : -INFINITY;
+    float tm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+    tm = fmaxf(tm, __shfl_xor(tm, 16));
+    tm = fmaxf(tm, __shfl_xor(tm, 32));
+    const float m_new = fmaxf(m, tm);
+    const float m_ref = m_new == -INFINITY ? 0.f : m_new;  // a token that has seen no timestep yet
+    const float alpha = expf(m - m_ref);                   // exp(-inf) = 0 on its first timestep
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = expf(sv[r] - m_ref);
+    l = l * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f32x4 o = oacc[c][e];
+        o.x *= alpha; o.y *= alpha; o.z *= alpha; o.w *= alpha;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o = mfma16(pg_comp(vc_[c][s], e), p[s], o);
+        oacc[c][e] = o;
+      }
+    m = m_new;
+  };
+
+  for (int pt = wave; pt < n_pt; pt += 8) {
+    const int p1 = pt + 4, p2 = pt + 8;
+    if (p1 < n_pt) {
+      load_k(kf[1], p1);
+      load_v(vf[1], p1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tile(kf[0], vf[0], pt);
+    if (p1 < n_pt) {
+      if (p2 < n_pt) {
+        load_k(kf[0], p2);
+        load_v(vf[0], p2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      tile(kf[1], vf[1], p1);
+    }
+  }
+
+  // ---- merge the four waves' partials (fixed order) ---------------------------------------------
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (lj == 0) {
+    m_lds[wave][li] = m;
+    l_lds[wave][li] = l;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int d0 = 64 * c + 16 * lj;
+    if (d0 < HS) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 v = {pg_comp(oacc[c][0], r), pg_comp(oacc[c][1], r), pg_comp(oacc[c][2], r),
+                   pg_comp(oacc[c][3], r)};
+        *(f32x4*)&o_lds[wave][li][d0 + 4 * r] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const int tok = tid & 15;
+  if (t0 + tok < a.T) {
+    const float m0 = m_lds[0][tok], m1 = m_lds[1][tok], m2 = m_lds[2][tok], m3 = m_lds[3][tok];
+    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));  // finite: a token sees its own timestep
+    const float f0 = expf(m0 - M), f1 = expf(m1 - M), f2 = expf(m2 - M), f3 = expf(m3 - M);
+    const float L = ((f0 * l_lds[0][tok] + f1 * l_lds[1][tok]) + f2 * l_lds[2][tok]) + f3 * l_lds[3][tok];
+    for (int grp = tid >> 4; grp < HS / 4; grp += 16) {
+      const f32x4 o0 = *(const f32x4*)&o_lds[0][tok][4 * grp], o1 = *(const f32x4*)&o_lds[1][tok][4 * grp],
+                  o2 = *(const f32x4*)&o_lds[2][tok][4 * grp], o3 = *(const f32x4*)&o_lds[3][tok][4 * grp];
+      f32x4 r;
+      r.x = (((f0 * o0.x + f1 * o1.x) + f2 * o2.x) + f3 * o3.x) / L;
+      r.y = (((f0 * o0.y + f1 * o1.y) + f2 * o2.y) + f3 * o3.y) / L;
+      r.z = (((f0 * o0.z + f1 * o1.z) + f2 * o2.z) + f3 * o3.z) / L;
+      r.w = (((f0 * o0.w + f1 * o1.w) + f2 * o2.w) + f3 * o3.w) / L;
+      const int k = h * HS + 4 * grp, t = t0 + tok;
+      const size_t at = a.layout == KH_PA_ROWS ? (size_t)t * a.dim + k
+                                               : pg_tiled_index(a.layout == KH_PA_TILED_Q8, k, t);
+      *(f32x4*)(a.out + at) = r;
+    }
+  }
+}
+
+static inline bool pg_attn_supported(int head_size) {
+  return head_size == 48 || head_size == 64 || head_size == 128;
+}
+static inline void launch_pg_attn(const KhPgAttnArgs& a, int head_size, hipStream_t s) {
+  const int grid = a.kv_heads * a.kv_mul * ((a.T + 15) / 16);
+  switch (head_size) {
+    case 48: hipLaunchKernelGGL(k_pg_attn<3>, dim3(grid), dim3(256), 0, s, a); break;
+    case 64: hipLaunchKernelGGL(k_pg_attn<4>, dim3(grid), dim3(256), 0, s, a); break;
+    case 128: hipLaunchKernelGGL(k_pg_attn<8>, dim3(grid), dim3(256), 0, s, a); break;
+    default: break;
+  }
+}

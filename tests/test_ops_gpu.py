@@ -320,6 +320,43 @@ def test_mha_long_context_multi_chunk(gpu, oracle):
         np.testing.assert_allclose(host(out2), oo, rtol=0, atol=3e-5)
 
 
+@pytest.mark.parametrize("heads,kv_heads,hs", [(8, 2, 64), (4, 4, 128), (6, 6, 48), (14, 2, 64)])
+def test_mha_prefill_mfma_vs_oracle(gpu, oracle, heads, kv_heads, hs):
+    """kh_mha_prefill_f32 (kh_pattn.h: q.K^T and P.V on v_mfma_f32_16x16x4_f32, online softmax) against
+    the oracle's one-query-at-a-time MHA (cpu/mha_kernel.cpp:5-61) for every token of the slice:
+    slices that start at 0, at a position that is not a multiple of the 16-timestep tile, deep in
+    the cache; token counts with partial tiles; a spiked key that forces the running-max rescale
+    in a LATER tile; GQA / MHA head mappings and the three head sizes."""
+    from kuiperllama_amd import ops
+    seq, layers = 1500, 2
+    rng = np.random.default_rng(heads * 10 + hs)
+    kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+    kc = rng.standard_normal((layers, seq, kv_dim)).astype(np.float32)
+    vc = rng.standard_normal((layers, seq, kv_dim)).astype(np.float32)
+    qs = rng.standard_normal((256, dim)).astype(np.float32)
+    kc[1, 700, :hs] = 3.0 * qs[3, :hs]  # every head of kv group 0, token 3: a huge score at t = 700
+    kcd, vcd = dev(kc, gpu), dev(vc, gpu)
+    for layer, pos0, n in ((0, 0, 1), (0, 0, 16), (0, 0, 37), (0, 0, 128), (1, 5, 100), (1, 690, 33),
+                           (1, 1244, 256), (0, 1499, 1)):
+        q = np.ascontiguousarray(qs[:n])
+        out = torch.full((n, dim), float("nan"), device=gpu)
+        ops.mha_prefill(pos0, n, heads, layer, seq, kv_dim, kv_mul, hs, out, dev(q, gpu), kcd, vcd)
+        got = host(out)
+        for t in sorted({0, 1, n // 2, n - 2, n - 1} & set(range(n))):
+            oo, _ = oracle.mha(pos0 + t, heads, layer, seq, kv_dim, kv_mul, hs, q[t], kc, vc,
+                               acc=oracle.ACC_F64)
+            np.testing.assert_allclose(got[t], oo, rtol=0, atol=3e-5,
+                                       err_msg=f"layer {layer} pos0 {pos0} n {n} t {t}")
+        assert np.isfinite(got).all()
+    # argument errors: unsupported head size, slice past the cache
+    out = torch.zeros(4, 4 * 32, device=gpu)
+    with pytest.raises(RuntimeError):
+        ops.mha_prefill(0, 4, 4, 0, 64, 4 * 32, 1, 32, out, out, out, out)
+    out = torch.zeros(4, dim, device=gpu)
+    with pytest.raises(RuntimeError):
+        ops.mha_prefill(seq - 2, 4, heads, 0, seq, kv_dim, kv_mul, hs, out, out, kcd, vcd)
+
+
 def test_mha_decode_time_split(gpu, oracle):
     """kh_mha_decode_f32 = the kernel the fused step launches: NS workgroups per head, the last
     arriver merges the partial (max, sum, o) triples.  Checks the 1 -> 2 -> 3... split

@@ -19,6 +19,8 @@ ap.add_argument("workload")
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--prefill", default="")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--prompt", type=int, default=128, help="prompt tokens per timed prefill")
+ap.add_argument("--pos0", type=int, default=0, help="position of the first prompt token")
 a = ap.parse_args()
 spec = binfmt.PRESETS[a.workload]
 img = binfmt.synth_image(spec, seed=1234, device=torch.device("cuda:0"))
@@ -28,9 +30,10 @@ if a.steps > 0:
     for _ in range(a.reps):
         m.generate([1, 263], a.steps, exec="graph")
 rng = np.random.default_rng(0)
-pp = [int(t) for t in rng.integers(0, spec.vocab_size, 128)]
+pp = [int(t) for t in rng.integers(0, spec.vocab_size, a.prompt)]
 for mode in [x for x in a.prefill.split(",") if x]:
     for _ in range(a.reps):
-        ms = m.time_prefill(pp, 0, mode)
-    print(f"prefill {mode}: {ms:.3f} ms for 128 tokens = {128e3 / ms:.0f} tok/s", flush=True)
+        ms = m.time_prefill(pp, a.pos0, mode)
+    at = f" at pos {a.pos0}" if a.pos0 else ""
+    print(f"prefill {mode}: {ms:.3f} ms for {a.prompt} tokens{at} = {a.prompt * 1e3 / ms:.0f} tok/s", flush=True)
 m.close()
