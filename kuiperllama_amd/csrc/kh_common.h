@@ -136,8 +136,15 @@ __device__ __forceinline__ float across_groups_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
-__device__ __forceinline__ int kh_wg() { return (int)blockDim.x; }
-__device__ __forceinline__ int kh_nwaves() { return (int)(blockDim.x >> 6); }
+// Workgroup width.  NOT blockDim.x: HIP's blockDim goes through __ockl_get_local_size, which selects
+// between the full and the remainder group size; when the optimiser sinks that select into the
+// ADDRESS (one load from "offset 12 or 18") the uniform-workgroup fold no longer matches and the
+// kernel starts with a vector global_load_ushort + s_waitcnt vmcnt(0) - a memory round trip
+// before the first useful load (seen in every decode kernel: +0.1-0.3 us each, 1-2 % of a token).
+// Every launch of this library uses full workgroups, so the hidden group-size word (a scalar
+// kernarg load) is the answer.
+__device__ __forceinline__ int kh_wg() { return (int)__builtin_amdgcn_workgroup_size_x(); }
+__device__ __forceinline__ int kh_nwaves() { return (int)(__builtin_amdgcn_workgroup_size_x() >> 6); }
 
 // Sum over the workgroup; every thread gets the result. red = LDS float[KH_WAVES_MAX+].
 // Two barriers so `red` can be reused immediately afterwards.

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int NM = EPI == KH_PG_SWIGLU ? 2 : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nw = (int)(blockDim.x >> 6);
+  const int nw = kh_nwaves();
   const int ks = nw / NM;
   const int mat = wave / ks, kpart = wave - mat * ks;
   const int i = lane & 15, h = lane >> 4;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
       for (int nt = 0; nt < NT; ++nt) red[((size_t)wave * NT + nt) * 64 + lane] = acc[r][nt];
       __syncthreads();
     }
-    for (int e = threadIdx.x; e < NT * 64; e += (int)blockDim.x) {
+    for (int e = threadIdx.x; e < NT * 64; e += kh_wg()) {
       const int nt = e >> 6, ln = e & 63;
       f32x4 v0, v1 = f32x4{0.f, 0.f, 0.f, 0.f};
       if (direct) {
