@@ -81,6 +81,10 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
   float* red = lds_red_ptr<QUANT>(xs, dim);
   const int lane = threadIdx.x & 63;
   const int hs = a.head_size, half = hs >> 1;
+  // head sizes are powers of two in every BASELINE config: shifts instead of the ~25-instruction
+  // integer division the work-item decode would otherwise run three times per row pair
+  const bool half_pow2 = (half & (half - 1)) == 0;
+  const int half_sh = __builtin_ctz((unsigned)half | 0x40000000u);
   const int npq = dim >> 1, npk = kv_dim >> 1;
   const int total = npq + 2 * npk;
   const Gemv<QUANT, U> g(dim, a.gshift);
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
     }
     if (which < 2 && rope_mode == KH_ROPE_HALF) {
       // cpu/rope_kernel.cpp:18-42: pair (head*hs + j, + hs/2), cache column 2j
-      const int head = pp / half, j = pp - head * half;
+      const int head = half_pow2 ? pp >> half_sh : pp / half, j = pp - head * half;
       r0 = head * hs + j;
       r1 = r0 + half;
       cidx = 2 * j;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
       // cpu/rope_kernel.cpp:98-121: pair (2i, 2i+1), cache column (2i % hs); v: plain pair
       r0 = 2 * pp;
       r1 = r0 + 1;
-      cidx = r0 % hs;
+      cidx = half_pow2 ? r0 & (hs - 1) : r0 % hs;
     }
   };
   auto pair = [&](int p) __attribute__((always_inline)) {

@@ -251,9 +251,11 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
   const int ce = cb + Q < g.Mc ? cb + Q : g.Mc;
   const int p0 = gp < total ? gp : 0;
   typename Gemv<QUANT, U>::Regs regs;
-  typename Gemv<QUANT, U>::Rows cur = PAIR(p0);
+  // the x loads leave FIRST - before the work-item decode of PAIR (k_qkv: an integer division and
+  // three-way selects, ~80 instructions the compiler otherwise hoists above them)
   ISSUE();
-  __builtin_amdgcn_sched_barrier(0);  // keep the x loads ahead of the weight loads in the queue
+  __builtin_amdgcn_sched_barrier(0);  // keep the x loads ahead of everything else, the weight loads included
+  typename Gemv<QUANT, U>::Rows cur = PAIR(p0);
   // unconditional (an idle wave re-reads pair 0): a branch here would make the compiler merge
   // the vmcnt state of both paths and wait vmcnt(0) — i.e. for the weights — before using x.
   // The loads stay in flight across the staging barriers.
