@@ -24,12 +24,18 @@ def default_workload(world: int) -> str:
     return REPLICA_WORKLOAD if world > 1 else SINGLE_WORKLOAD
 
 
+def _dist():
+    """torch.distributed when a process group is up (N > 1, or a test that brought one up), else None."""
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
 def backend_in_use(world: int) -> str:
     """Collective backend the timing protocol actually runs on ("none" for one process)."""
-    if world <= 1:
-        return "none"
-    import torch.distributed as dist
-    return str(dist.get_backend()) if dist.is_initialized() else "uninitialised"
+    dist = _dist()
+    if dist is not None:
+        return str(dist.get_backend())
+    return "none" if world <= 1 else "uninitialised"
 
 
 def init_from_env(backend: str, device: torch.device | None = None) -> Tuple[int, int, int]:
@@ -62,9 +68,7 @@ def timed_replica_run(run: Callable[[], float | None], steps: int, world: int,
     """Time `run()` (one replica's K steps) bracketed by barrier + device sync on both sides;
     returns (max wall seconds over ranks, aggregate steps/s = world*steps / max wall)."""
     import time
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # type: ignore[no-redef]
+    dist = _dist()  # None for a single process without a group
     sync()
     if dist is not None:
         dist.barrier()
@@ -87,12 +91,12 @@ def timed_replica_run(run: Callable[[], float | None], steps: int, world: int,
 def gather_per_replica(value: float, world: int, device: torch.device) -> list:
     """Every rank's `value` (its own wall seconds, tok/s ...), in rank order, on every rank.
     Measurement plumbing only - the data path exchanges nothing."""
-    if world <= 1:
+    dist = _dist()
+    if dist is None:
         return [float(value)]
-    import torch.distributed as dist
     red_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
     mine = torch.tensor([value], dtype=torch.float64, device=red_dev)
-    out = [torch.zeros_like(mine) for _ in range(world)]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return [float(t.item()) for t in out]
 
@@ -105,8 +109,7 @@ def spread(per_replica: list) -> dict:
 
 
 def shutdown(world: int) -> None:
-    if world > 1:
-        import torch.distributed as dist
-        if dist.is_initialized():
-            dist.barrier()
-            dist.destroy_process_group()
+    dist = _dist()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()

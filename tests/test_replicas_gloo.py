@@ -87,3 +87,45 @@ def test_single_process_path_needs_no_process_group():
     wall, agg = replicas.timed_replica_run(lambda: None, 10, 1, torch.device("cpu"), lambda: None)
     assert wall > 0 and abs(agg - 10 / wall) < 1e-6
     replicas.shutdown(1)
+
+
+@pytest.mark.gpu
+def test_timing_protocol_on_rccl_single_rank(gpu):
+    """The N > 1 bench path on the backend it really uses: a one-rank RCCL ("nccl") process group on
+    the GPU box carries the barrier, the max-reduce of the wall time and the per-replica gather on
+    DEVICE tensors, and the bench line would report that backend.  (N > 1 itself is covered by the
+    world_size-2 gloo test above; the driver runs the 8-GPU launch.)"""
+    import socket
+    import torch.distributed as dist
+    from kuiperllama_amd import replicas
+    assert not dist.is_initialized()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    old = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+        assert replicas.backend_in_use(1) == "nccl"
+        x = torch.zeros(1 << 20, device=gpu)
+
+        def run():
+            for _ in range(8):
+                x.add_(1.0)
+
+        wall, agg = replicas.timed_replica_run(run, 8, 1, gpu, torch.cuda.synchronize)
+        assert wall > 0 and abs(agg - 8 / wall) < 1e-6 * agg
+        per = replicas.gather_per_replica(123.5, 1, gpu)
+        assert per == [123.5]
+        assert replicas.spread(per)["spread_frac"] == 0.0
+        assert float(x[0]) == 8.0
+        replicas.shutdown(1)
+        assert not dist.is_initialized()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
