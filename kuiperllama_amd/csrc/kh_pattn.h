@@ -3,7 +3,7 @@
 // The reference computes attention one query token at a time (cpu/mha_kernel.cpp:5-61,
 // cuda/mha_kernel.cu:47-110: score = q.k * 1/sqrt(hs), softmax over 0..pos, out = sum p_t v_t).
 // With T prompt tokens in flight, q.K^T and P.V are real GEMMs: here one workgroup owns (head h,
-// 16 query tokens) and its four waves split the key/value timesteps in 16-position tiles; both
+// 16 query tokens) and its four or eight waves split the key/value timesteps in 16-position tiles; both
 // contractions run on v_mfma_f32_16x16x4_f32 (exact fp32 fmaf chains), the softmax is the online
 // form the decode kernel already uses (running max m, running sum l, rescale by exp(m - m')).
 //
@@ -23,7 +23,7 @@
 // Row statistics: a token's scores sit in 4 registers x 4 lane groups (l>>4); the tile maximum is
 // combined across the groups with two ds_bpermute, so every lane of a token uses the same m and
 // the P values fed to the matrix core are consistently scaled.  The row sum is kept per lane and
-// combined once at the end.  The four waves' (m, l, O) partials merge through LDS in fixed order.
+// combined once at the end.  The waves' (m, l, O) partials merge through LDS in fixed order.
 //
 // Output goes straight into the tiled activation slab the wo GEMM reads (pg_tiled_index).
 #pragma once
@@ -39,13 +39,13 @@ struct KhPgAttnArgs {
 };
 enum { KH_PA_TILED_F32 = 0, KH_PA_TILED_Q8 = 1, KH_PA_ROWS = 2 };
 
-template <int HB /* head_size / 16 */>
-__global__ __launch_bounds__(256) void k_pg_attn(const KhPgAttnArgs a) {
+template <int HB /* head_size / 16 */, int NW /* waves that split the timesteps: 4 or 8 */>
+__global__ __launch_bounds__(64 * NW) void k_pg_attn(const KhPgAttnArgs a) {
   constexpr int HS = 16 * HB;
   constexpr int NC = (HS + 63) / 64;  // 64-wide chunks of the head dimension on the P.V side
   constexpr int LDO = HS + 4;         // LDS row stride (floats): float4 rows of 16 tokens hit distinct banks
-  __shared__ __attribute__((aligned(16))) float o_lds[4][16][LDO];
-  __shared__ float m_lds[4][16], l_lds[4][16];
+  __shared__ __attribute__((aligned(16))) float o_lds[NW][16][LDO];
+  __shared__ float m_lds[NW][16], l_lds[NW][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lj = lane >> 4;
   // workgroup -> (kv group g, head-in-group j, token tile tt); b % 8 is the XCD: the kv_mul heads
@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void k_pg_attn(const KhPgAttnArgs a) {
   const int t_last = t0 + 15 < a.T - 1 ? t0 + 15 : a.T - 1;
   const int p_last = a.pos0 + t_last;  // last timestep any token of this tile attends to
   const int n_pt = (p_last >> 4) + 1;  // 16-position tiles, aligned at timestep 0
-  const float scale = 1.0f / sqrtf((float)HS);
+  // scores are kept in the log2 domain (score * 1/sqrt(hs) * log2(e)) so that the softmax runs on the
+  // hardware exp2 (v_exp_f32), like the GQA decode path of kh_attn.h: exp(s - m) == exp2(s2 - m2)
+  const float scale = (1.0f / sqrtf((float)HS)) * 1.4426950408889634f;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   const int tq = t0 + li < a.T ? t0 + li : a.T - 1;  // this lane's query token (column of both
@@ -121,10 +123,10 @@ __global__ __launch_bounds__(256) void k_pg_attn(const KhPgAttnArgs a) {
     tm = fmaxf(tm, __shfl_xor(tm, 32));
     const float m_new = fmaxf(m, tm);
     const float m_ref = m_new == -INFINITY ? 0.f : m_new;  // a token that has seen no timestep yet
-    const float alpha = expf(m - m_ref);                   // exp(-inf) = 0 on its first timestep
+    const float alpha = __builtin_amdgcn_exp2f(m - m_ref);  // exp2(-inf) = 0 on its first timestep
     float p[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r] = expf(sv[r] - m_ref);
+    for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sv[r] - m_ref);
     l = l * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(256) void k_pg_attn(const KhPgAttnArgs a) {
     m = m_new;
   };
 
-  for (int pt = wave; pt < n_pt; pt += 8) {
-    const int p1 = pt + 4, p2 = pt + 8;
+  for (int pt = wave; pt < n_pt; pt += 2 * NW) {
+    const int p1 = pt + NW, p2 = pt + 2 * NW;
     if (p1 < n_pt) {
       load_k(kf[1], p1);
       load_v(vf[1], p1);
@@ -179,18 +181,23 @@ __global__ __launch_bounds__(256) void k_pg_attn(const KhPgAttnArgs a) {
   __syncthreads();
   const int tok = tid & 15;
   if (t0 + tok < a.T) {
-    const float m0 = m_lds[0][tok], m1 = m_lds[1][tok], m2 = m_lds[2][tok], m3 = m_lds[3][tok];
-    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));  // finite: a token sees its own timestep
-    const float f0 = expf(m0 - M), f1 = expf(m1 - M), f2 = expf(m2 - M), f3 = expf(m3 - M);
-    const float L = ((f0 * l_lds[0][tok] + f1 * l_lds[1][tok]) + f2 * l_lds[2][tok]) + f3 * l_lds[3][tok];
-    for (int grp = tid >> 4; grp < HS / 4; grp += 16) {
-      const f32x4 o0 = *(const f32x4*)&o_lds[0][tok][4 * grp], o1 = *(const f32x4*)&o_lds[1][tok][4 * grp],
-                  o2 = *(const f32x4*)&o_lds[2][tok][4 * grp], o3 = *(const f32x4*)&o_lds[3][tok][4 * grp];
-      f32x4 r;
-      r.x = (((f0 * o0.x + f1 * o1.x) + f2 * o2.x) + f3 * o3.x) / L;
-      r.y = (((f0 * o0.y + f1 * o1.y) + f2 * o2.y) + f3 * o3.y) / L;
-      r.z = (((f0 * o0.z + f1 * o1.z) + f2 * o2.z) + f3 * o3.z) / L;
-      r.w = (((f0 * o0.w + f1 * o1.w) + f2 * o2.w) + f3 * o3.w) / L;
+    float M = m_lds[0][tok];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, m_lds[w][tok]);  // finite: a token sees its own timestep
+    float f[NW], L = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      f[w] = __builtin_amdgcn_exp2f(m_lds[w][tok] - M);  // waves without a timestep: m = -inf -> 0
+      L += f[w] * l_lds[w][tok];
+    }
+    for (int grp = tid >> 4; grp < HS / 4; grp += 4 * NW) {
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const f32x4 o = *(const f32x4*)&o_lds[w][tok][4 * grp];
+        r.x += f[w] * o.x; r.y += f[w] * o.y; r.z += f[w] * o.z; r.w += f[w] * o.w;
+      }
+      r.x /= L; r.y /= L; r.z /= L; r.w /= L;
       const int k = h * HS + 4 * grp, t = t0 + tok;
       const size_t at = a.layout == KH_PA_ROWS ? (size_t)t * a.dim + k
                                                : pg_tiled_index(a.layout == KH_PA_TILED_Q8, k, t);
@@ -204,10 +211,12 @@ static inline bool pg_attn_supported(int head_size) {
 }
 static inline void launch_pg_attn(const KhPgAttnArgs& a, int head_size, hipStream_t s) {
   const int grid = a.kv_heads * a.kv_mul * ((a.T + 15) / 16);
+  // 8 waves (two per SIMD: one wave's softmax fills the other's MFMA shadow) where the registers
+  // allow it; head size 128 keeps 4
   switch (head_size) {
-    case 48: hipLaunchKernelGGL(k_pg_attn<3>, dim3(grid), dim3(256), 0, s, a); break;
-    case 64: hipLaunchKernelGGL(k_pg_attn<4>, dim3(grid), dim3(256), 0, s, a); break;
-    case 128: hipLaunchKernelGGL(k_pg_attn<8>, dim3(grid), dim3(256), 0, s, a); break;
+    case 48: hipLaunchKernelGGL((k_pg_attn<3, 8>), dim3(grid), dim3(512), 0, s, a); break;
+    case 64: hipLaunchKernelGGL((k_pg_attn<4, 8>), dim3(grid), dim3(512), 0, s, a); break;
+    case 128: hipLaunchKernelGGL((k_pg_attn<8, 4>), dim3(grid), dim3(256), 0, s, a); break;
     default: break;
   }
 }
