@@ -1299,14 +1299,16 @@ void pg_launch(kh_model* m, int rows_total, bool r2_ok, const KhPgGemmArgs& a) {
   PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 4 : 16, q);
   {  // tuning hook: KH_PG_SHAPE_<QKV|RESID|SWIGLU>="R,NT,ks" overrides the heuristic
     static const char* const names[3] = {"KH_PG_SHAPE_QKV", "KH_PG_SHAPE_RESID", "KH_PG_SHAPE_SWIGLU"};
-    if (const char* ov = getenv(names[EPI])) {
+    static const char* const ov = getenv(names[EPI]);  // read once per process (one static per EPI)
+    if (ov) {
       int R = 0, NT = 0, ks = 0;
       if (sscanf(ov, "%d,%d,%d", &R, &NT, &ks) == 3 && ((R == 2 && (NT == 2 || NT == 4 || NT == 8) && r2_ok) || (R == 1 && NT == 4)) &&
           (ks == 1 || ks == 2 || ks == 4 || ks == 8) && ks * nm * 64 <= KH_PG_WG_MAX(q))
         sh = PgShape{R, NT, ks, ((a.T + 15) / 16 + NT - 1) / NT};
     }
   }
-  if (getenv("KH_PG_DEBUG"))
+  static const bool debug = getenv("KH_PG_DEBUG") != nullptr;
+  if (debug)
     fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d (%d wgs x %d waves)\n", EPI,
             rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, rows_total / (16 * sh.R) * sh.slices,
             nm * sh.ks);
