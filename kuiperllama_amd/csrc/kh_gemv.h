@@ -240,7 +240,12 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
   const int vb = (int)blockIdx.x, vgrid = (int)gridDim.x;
   static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
   const int PPW = kh_nwaves() / SPLIT;  // pairs per workgroup per iteration
-  const int wave = threadIdx.x >> 6;
+  // The wave index is uniform by construction.  Telling the compiler (readfirstlane) moves the
+  // work-item arithmetic - pair index, row addresses, loop control - to the scalar unit: same-box A/B
+  // (profiles/r2_scalar_wave_ab.txt) fp32 +0.6 % (cls 154 -> 151 us, qkv 6.5 -> 6.4), but the int8
+  // kernels, whose loop is VALU-heavier, lose 0.7 % (ffn13 18.0 -> 18.4 us) - so fp32 only.
+  const int wave = QUANT ? (int)(threadIdx.x >> 6)
+                         : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int part = wave & (SPLIT - 1);
   const int gp = vb * PPW + wave / SPLIT;
   const int np = vgrid * PPW;
