@@ -141,6 +141,38 @@ def test_demo_cli_text_prompt_with_bpe_tokenizer_json(gpu, oracle, tmp_path):
     assert lines[1].rstrip(" ") == tok.decode(want).rstrip(" ")
 
 
+@pytest.mark.gpu
+def test_demo_cli_qwen_family_like_main_qwen(gpu, oracle, tmp_path):
+    """--family qwen2 = demo/main_qwen.cpp: q/k/v biases, the Qwen2 byte-level BPE (no BOS), prompt "hi!"
+    (main_qwen.cpp:64), `words` seeded with the first prompt token (:12,:18) and the extra
+    steps / duration lines (:73-74); ids equal the oracle's run on the same prompt ids."""
+    import torch
+    from conftest import GOLDEN
+    from kuiperllama_amd import binfmt
+    from kuiperllama_amd.tokenizer import BpeTokenizer, QWEN2
+    tok_path = os.path.join(GOLDEN, "bpe_qwen2_like.json")
+    tok = BpeTokenizer.from_file(tok_path, QWEN2)
+    spec = binfmt.ModelSpec(256, 512, 2, 4, 2, tok.vocab_size, 128, True, binfmt.FAMILY_QWEN2, False, 64,
+                            binfmt.ROPE_HALF, 1000000.0, 1e-6, "demo-qwen")
+    img = binfmt.synth_image(spec, seed=13, device=torch.device("cpu")).numpy()
+    path = tmp_path / "m.bin"
+    img.tofile(path)
+    text = "hi! how are you"
+    prompt = tok.encode(text)
+    assert len(prompt) >= 2
+    want = oracle.OracleModel.from_spec(img, spec).generate(prompt, 30, stop=tok.stop_ids)
+    exe = build.build_demo()
+    r = subprocess.run([exe, str(path), "--family", "qwen2", "--rope", "half", "--theta", "1000000", "--eps", "1e-6",
+                        "--steps", "30", "--tokenizer-json", tok_path, "--text", text],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.split("\n")
+    ids = [int(t) for t in lines[2].split()]
+    assert ids == [prompt[0]] + want
+    assert any(ln.startswith("steps:%d" % len(want)) for ln in lines)
+    assert any(ln.startswith("duration:") for ln in lines)
+
+
 def test_demo_cli_builds_and_fails_loudly_without_gpu(tmp_path):
     import torch
     if torch.cuda.is_available():

@@ -164,6 +164,12 @@ int main(int argc, char** argv) {
     kh_model_destroy(m);
     return 1;
   }
+  if (o.family == KH_FAMILY_QWEN2 && !prompt.empty()) {
+    // demo/main_qwen.cpp:12,18 seeds `next` with the first prompt token and pushes it into `words`
+    // before the loop (main.cpp starts from next = -1): the Qwen demo's output begins with it
+    words.insert(words.begin(), prompt[0]);
+    ++n;
+  }
   if (tok) {  // main.cpp:43-45: printf("%s ", model.decode(words))
     std::vector<char> buf((size_t)n * 16 + 16);
     int64_t len = 0;
@@ -180,7 +186,9 @@ int main(int argc, char** argv) {
   }
   for (int i = 0; i < n; ++i) std::printf("%d ", words[i]);
   const double dur = std::chrono::duration<double>(t1 - t0).count();
-  std::printf("\nsteps/s:%lf\n", (double)n / dur);
+  const int steps_done = n - (o.family == KH_FAMILY_QWEN2 && !prompt.empty() ? 1 : 0);
+  std::printf("\nsteps/s:%lf\n", (double)steps_done / dur);
+  if (o.family == KH_FAMILY_QWEN2) std::printf("\nsteps:%d\n\nduration:%lf\n", steps_done, dur);  // main_qwen.cpp:73-74
   std::fprintf(stderr, "(device time of the step loop: %.3f ms)\n", gpu_ms);
   kh_model_destroy(m);
   return 0;
