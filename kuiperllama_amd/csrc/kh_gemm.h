@@ -74,7 +74,16 @@ struct KhPgGemmArgs {
   int rows0, rows1;  // QKV: rows of wq, rows of wk (= rows of wv); else rows0 = rows
   int ldo, K, T, pos0, gshift;
   int b_tiled;       // B is a tiled slab (else row-major [T][K])
+  // QKV only: RoPE fused into the epilogue (0 = off: k_pg_rope runs afterwards).  KH_PG_ROPE_PAIRS:
+  // the pair (2i, 2i+1) sits in one lane's float4 (interleaved mode, cpu/rope_kernel.cpp:98-121).
+  // KH_PG_ROPE_TILES: half mode (rope_kernel.cpp:18-42) pairs row j with j + hs/2 - a wave's R = 2
+  // tiles are then tile t and tile t + hs/32 of the same head instead of two neighbours, so both
+  // partners sit in the same lane and register index.
+  int rope, head_size;
+  const float* sin_cache;
+  const float* cos_cache;
 };
+enum { KH_PG_ROPE_OFF = 0, KH_PG_ROPE_PAIRS = 1, KH_PG_ROPE_TILES = 2 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -243,10 +252,18 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
   const int mat = wave / ks, kpart = wave - mat * ks;
   const int i = lane & 15, h = lane >> 4;
   const int K = a.K;
-  const int row0 = (int)blockIdx.x * (16 * R);  // first row of the tile in the stacked output
+  // first row of the wave's tile r in the stacked output: neighbours, or (half-mode fused RoPE) the
+  // tile and its rotation partner hs/2 rows further down the same head
+  int row0 = (int)blockIdx.x * (16 * R), rstep = 16;
+  if (EPI == KH_PG_QKV && R == 2 && NT <= 4 && a.rope == KH_PG_ROPE_TILES) {
+    const int nb = a.head_size >> 5;  // workgroups per head
+    const int g = (int)blockIdx.x / nb;
+    row0 = g * a.head_size + ((int)blockIdx.x - g * nb) * 16;
+    rstep = a.head_size >> 1;
+  }
   const int tok0 = (int)blockIdx.y * (16 * NT);
-  // weight matrix of this tile (a tile never straddles two matrices: their row counts are
-  // multiples of 16 * R, checked by the host)
+  // weight matrix of this workgroup (its tiles never straddle two matrices: row counts are multiples
+  // of 16 * R - of the head size with paired tiles -, checked by the host)
   KhLin W = a.w[mat];
   int wr0 = row0;
   if (EPI == KH_PG_QKV) {
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
     const int b1 = __builtin_amdgcn_readfirstlane((int)((long)(kpart + 1) * nb / ks));
     const float* wrow[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) wrow[r] = (const float*)W.w + (size_t)(wr0 + 16 * r + i) * K + 4 * h;
+    for (int r = 0; r < R; ++r) wrow[r] = (const float*)W.w + (size_t)(wr0 + rstep * r + i) * K + 4 * h;
     if (a.b_tiled) {
       B = PgBAddr{a.B + (size_t)(tok0 + i) * 16 + 4 * h, 256, (size_t)KH_PG_TMAX * 16, 0};
     } else {
@@ -287,8 +304,8 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
     const float* srow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      wrow[r] = (const int8_t*)W.w + (size_t)(wr0 + 16 * r + i) * K + 16 * h;
-      srow[r] = W.scales + (size_t)(wr0 + 16 * r + i) * nb;
+      wrow[r] = (const int8_t*)W.w + (size_t)(wr0 + rstep * r + i) * K + 16 * h;
+      srow[r] = W.scales + (size_t)(wr0 + rstep * r + i) * nb;
     }
     if (a.b_tiled) {
       B = PgBAddr{a.B + (size_t)(tok0 + i) * 16 + 4 * h, 256, (size_t)4 * KH_PG_TMAX * 16,
@@ -302,6 +319,10 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
   //      one 16-row tile at a time (the LDS area holds one tile row of partials) -------------------
   f32x4* red = (f32x4*)smem_raw;
   const bool direct = nw == 1;
+  // fused half-mode RoPE: tile 0's rows wait here for their partners in tile 1 (NT <= 4 only: with
+  // eight token tiles the 32 extra registers push the epilogue into scratch; the host then keeps k_pg_rope)
+  constexpr bool TILE_ROPE = EPI == KH_PG_QKV && R == 2 && NT <= 4;
+  f32x4 keep[TILE_ROPE ? NT : 1];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (!direct) {
@@ -310,7 +331,10 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
       for (int nt = 0; nt < NT; ++nt) red[((size_t)wave * NT + nt) * 64 + lane] = acc[r][nt];
       __syncthreads();
     }
-    for (int e = threadIdx.x; e < NT * 64; e += kh_wg()) {
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {  // NT * 64 elements over >= 64 threads (static trip count: keep[])
+      const int e = (int)threadIdx.x + it * kh_wg();
+      if (e >= NT * 64) break;
       const int nt = e >> 6, ln = e & 63;
       f32x4 v0, v1 = f32x4{0.f, 0.f, 0.f, 0.f};
       if (direct) {
@@ -333,10 +357,10 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
         }
       }
       const int tok = tok0 + 16 * nt + (ln & 15);
-      if (tok >= a.T) continue;
-      const int orow = row0 + 16 * r + 4 * (ln >> 4);  // first of the 4 output rows
+      if (tok >= a.T) continue;  // (padding tokens: nothing kept, nothing stored)
+      const int orow = row0 + rstep * r + 4 * (ln >> 4);  // first of the 4 output rows
       if (EPI == KH_PG_QKV) {
-        // bias after the matmul, before RoPE (matmul.cpp:74-77); RoPE itself: k_pg_rope
+        // bias after the matmul, before RoPE (matmul.cpp:74-77)
         int which = 0, rr = orow;
         if (rr >= a.rows0 + a.rows1) {
           which = 2;
@@ -352,7 +376,39 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
         }
         float* dst = which == 0 ? a.out + (size_t)tok * a.ldo
                                 : (which == 1 ? a.kc : a.vc) + (size_t)(a.pos0 + tok) * a.rows1;
-        *(f32x4*)(dst + rr) = v0;
+        const int hs = a.head_size;
+        const float* sn = a.sin_cache + (size_t)(a.pos0 + tok) * hs;
+        const float* cs = a.cos_cache + (size_t)(a.pos0 + tok) * hs;
+        if (which < 2 && a.rope == KH_PG_ROPE_PAIRS) {
+          // interleaved: the float4 holds pairs (rr, rr+1), (rr+2, rr+3); cache column = row in head
+          const int c = rr % hs;
+          const float s0 = sn[c], c0 = cs[c], s1 = sn[c + 2], c1 = cs[c + 2];
+          f32x4 o;
+          o.x = v0.x * c0 - v0.y * s0;
+          o.y = v0.x * s0 + v0.y * c0;
+          o.z = v0.z * c1 - v0.w * s1;
+          o.w = v0.z * s1 + v0.w * c1;
+          *(f32x4*)(dst + rr) = o;
+        } else if (TILE_ROPE && which < 2 && a.rope == KH_PG_ROPE_TILES) {
+          if (r == 0) {
+            keep[TILE_ROPE ? it : 0] = v0;  // rows head*hs + j .. + 3 (j < hs/2): rotated when tile 1 arrives
+          } else {
+            // this tile holds the partners, rows head*hs + hs/2 + j .. + 3; cache column 2 * j
+            const int half = hs >> 1, j = (rr - half) % hs;
+            const f32x4 lo = keep[TILE_ROPE ? it : 0];
+            f32x4 olo, ohi;
+            const float s0 = sn[2 * j], c0 = cs[2 * j], s1 = sn[2 * j + 2], c1 = cs[2 * j + 2];
+            const float s2 = sn[2 * j + 4], c2 = cs[2 * j + 4], s3 = sn[2 * j + 6], c3 = cs[2 * j + 6];
+            olo.x = lo.x * c0 - v0.x * s0; ohi.x = lo.x * s0 + v0.x * c0;
+            olo.y = lo.y * c1 - v0.y * s1; ohi.y = lo.y * s1 + v0.y * c1;
+            olo.z = lo.z * c2 - v0.z * s2; ohi.z = lo.z * s2 + v0.z * c2;
+            olo.w = lo.w * c3 - v0.w * s3; ohi.w = lo.w * s3 + v0.w * c3;
+            *(f32x4*)(dst + rr - half) = olo;
+            *(f32x4*)(dst + rr) = ohi;
+          }
+        } else {
+          *(f32x4*)(dst + rr) = v0;
+        }
       } else if (EPI == KH_PG_RESID) {
         f32x4* dst = (f32x4*)(a.out + (size_t)tok * a.ldo + orow);
         f32x4 x = *dst;

@@ -1292,8 +1292,9 @@ void pg_launch_cfg(const PgShape& sh, int tiles, int wg, hipStream_t s, const Kh
   else if (sh.R == 2) go(k_pg_gemm<Q, 2, 2, EPI>);
   else go(k_pg_gemm<Q, 1, 4, EPI>);
 }
+// returns whether the QKV epilogue rotates q / k itself (else k_pg_rope has to follow)
 template <int EPI>
-void pg_launch(kh_model* m, int rows_total, bool r2_ok, const KhPgGemmArgs& a) {
+bool pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
   const bool q = m->cfg.is_quant;
   const int nm = EPI == KH_PG_SWIGLU ? 2 : 1;
   PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 4 : 16, q);
@@ -1312,9 +1313,12 @@ void pg_launch(kh_model* m, int rows_total, bool r2_ok, const KhPgGemmArgs& a) {
     fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d (%d wgs x %d waves)\n", EPI,
             rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, rows_total / (16 * sh.R) * sh.slices,
             nm * sh.ks);
+  if (EPI == KH_PG_QKV && a.rope == KH_PG_ROPE_TILES && (sh.R != 2 || sh.NT > 4))
+    a.rope = KH_PG_ROPE_OFF;  // no partner tile in the wave / no registers to hold it: k_pg_rope follows
   const int tiles = rows_total / (16 * sh.R);
   if (q) pg_launch_cfg<true, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a);
   else pg_launch_cfg<false, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a);
+  return EPI == KH_PG_QKV && a.rope != KH_PG_ROPE_OFF;
 }
 // forward of T (<= KH_PG_TMAX) prompt tokens at positions pos0..: fills their K/V cache rows
 void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0) {
@@ -1328,21 +1332,30 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
   // attention of the slice: MFMA kernel (kh_pattn.h) unless KH_PG_ATTN=0 or an odd head size
   static const bool attn_env = [] { const char* e = getenv("KH_PG_ATTN"); return !(e && e[0] == '0'); }();
   const bool mfma_attn = attn_env && pg_attn_supported(c.head_size);
+  static const bool rope_fuse_env = [] { const char* e = getenv("KH_PG_ROPE_FUSE"); return !(e && e[0] == '0'); }();
   for (int l = 0; l < c.layer_num; ++l) {
     const LayerW& W = m->layers[l];
     float* kc = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
     float* vc = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
     rmsnorm(W.att_norm);
+    bool rope_fused = false;
     {
       KhPgGemmArgs a{};
       a.w[0] = W.wq; a.w[1] = W.wk; a.w[2] = W.wv;
       a.B = m->pg_xn; a.b_tiled = 1; a.out = m->pg_q; a.kc = kc; a.vc = vc;
       a.rows0 = c.dim; a.rows1 = c.kv_dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.pos0 = pos0;
       a.gshift = m->gshift;
-      pg_launch<KH_PG_QKV>(m, c.dim + 2 * c.kv_dim, c.dim % 32 == 0 && c.kv_dim % 32 == 0, a);
+      // RoPE in the epilogue: interleaved pairs sit in one lane's float4; half-mode partners need the
+      // paired-tile mapping (R = 2, head size a multiple of 32).  KH_PG_ROPE_FUSE=0: separate kernel.
+      a.head_size = c.head_size; a.sin_cache = m->sin_cache; a.cos_cache = m->cos_cache;
+      a.rope = !rope_fuse_env ? KH_PG_ROPE_OFF
+               : (c.rope_mode == KH_ROPE_HALF ? (c.head_size % 32 == 0 ? KH_PG_ROPE_TILES : KH_PG_ROPE_OFF)
+                                              : KH_PG_ROPE_PAIRS);
+      rope_fused = pg_launch<KH_PG_QKV>(m, c.dim + 2 * c.kv_dim, c.dim % 32 == 0 && c.kv_dim % 32 == 0, a);
     }
-    hipLaunchKernelGGL(k_pg_rope, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_q, kc, m->sin_cache,
-                       m->cos_cache, c.dim, c.kv_dim, c.head_size, pos0, c.rope_mode);
+    if (!rope_fused)
+      hipLaunchKernelGGL(k_pg_rope, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_q, kc, m->sin_cache,
+                         m->cos_cache, c.dim, c.kv_dim, c.head_size, pos0, c.rope_mode);
     if (mfma_attn) {
       KhPgAttnArgs a{};
       a.q = m->pg_q; a.kc = kc; a.vc = vc; a.out = m->pg_att;
