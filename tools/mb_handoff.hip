@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_stage(Stage st, const float* __restrict
 }
 
 // (B) all stages in one persistent launch, tagged hand-off
-template <int K /* vector entries per thread = N / 256 */>
+template <int K /* vector entries per thread = N / 256 */, int SLEEP /* s_sleep units between poll rounds */>
 __global__ __launch_bounds__(256) void k_persist(const Stage* __restrict__ stages, int nstages, unsigned long long* xbuf,
                                                  int N, unsigned epoch0, int* err) {
   __shared__ __attribute__((aligned(16))) float xs[NMAX];
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_persist(const Stage* __restrict__ stage
         ok = true;
 #pragma unroll
         for (int k = 0; k < K; ++k) ok = ok && (unsigned)(p[k] >> 32) == tag;
-        if (!ok) __builtin_amdgcn_s_sleep(2);
+        if (!ok) __builtin_amdgcn_s_sleep(SLEEP);
       }
       if (!ok) *err = 1;  // bounded: never hang the box
 #pragma unroll
@@ -121,13 +121,13 @@ __global__ void k_tag(unsigned long long* xbuf, int N, unsigned tag) {
 }
 
 int main(int argc, char** argv) {
-  const int N = (argc > 1 && atoi(argv[1]) == 4096) ? 4096 : 2048;
+  const int N = 2048;
   hipStream_t S; CK(hipStreamCreate(&S));
   hipEvent_t E0, E1; CK(hipEventCreate(&E0)); CK(hipEventCreate(&E1));
   const size_t MB = 1 << 20;
   // a Llama-3.2-1B-like layer: qkv 25 MB, (attention stand-in: 1 MB), wo 16.8 MB, ffn13 134 MB, w2 67 MB
   const std::vector<std::vector<size_t>> sets = {
-      {25 * MB, 1 * MB, 17 * MB, 134 * MB, 67 * MB}, {4 * MB}, {16 * MB}, {64 * MB}};
+      {25 * MB, 1 * MB, 17 * MB, 134 * MB, 67 * MB}, {4 * MB, 3 * MB, 3 * MB, 35 * MB, 17 * MB}, {4 * MB}, {16 * MB}, {64 * MB}};
   char* pool; const size_t pool_bytes = 1024 * MB; CK(hipMalloc(&pool, pool_bytes)); CK(hipMemset(pool, 0, pool_bytes));
   float *xa, *xb; CK(hipMalloc(&xa, NMAX * 4)); CK(hipMalloc(&xb, NMAX * 4));
   CK(hipMemset(xa, 0, NMAX * 4)); CK(hipMemset(xb, 0, NMAX * 4));
@@ -135,7 +135,7 @@ int main(int argc, char** argv) {
   int* err; CK(hipMalloc(&err, 4)); CK(hipMemset(err, 0, 4));
   Stage* dstages; CK(hipMalloc(&dstages, 64 * sizeof(Stage)));
   printf("# vector length %d floats; tile 2 x %d KiB per wave; us per stage\n", N, U);
-  for (int grid : {256, 512, 1024}) {
+  for (int grid : {256, 512}) {  // 1024 workgroups with 32 KB of LDS each are not co-resident (the bounded spin times out)
     for (const auto& set : sets) {
       const int layers = set.size() > 1 ? 3 : 15;
       std::vector<Stage> st;
@@ -163,22 +163,24 @@ int main(int argc, char** argv) {
       }
       CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
       // (B) persistent, tagged hand-off (grid must be co-resident: <= 8 workgroups of 256 threads per CU)
-      float best_b = 1e30f;
+      float best_b[3] = {1e30f, 1e30f, 1e30f};
       unsigned epoch = 1;
-      for (int r = 0; r < 6; ++r) {
-        hipLaunchKernelGGL(k_tag, dim3((N + 255) / 256), dim3(256), 0, S, xbuf, N, epoch);
-        CK(hipEventRecord(E0, S));
-        if (N == 2048) hipLaunchKernelGGL(k_persist<8>, dim3(grid), dim3(256), 0, S, dstages, ns, xbuf, N, epoch, err);
-        else hipLaunchKernelGGL(k_persist<16>, dim3(grid), dim3(256), 0, S, dstages, ns, xbuf, N, epoch, err);
-        CK(hipEventRecord(E1, S)); CK(hipEventSynchronize(E1));
-        float ms; CK(hipEventElapsedTime(&ms, E0, E1)); if (r > 0 && ms < best_b) best_b = ms;
-        epoch += (unsigned)ns + 1;
-      }
+      for (int variant = 0; variant < 3; ++variant)
+        for (int r = 0; r < 5; ++r) {
+          hipLaunchKernelGGL(k_tag, dim3((N + 255) / 256), dim3(256), 0, S, xbuf, N, epoch);
+          CK(hipEventRecord(E0, S));
+          if (variant == 0) hipLaunchKernelGGL((k_persist<8, 2>), dim3(grid), dim3(256), 0, S, dstages, ns, xbuf, N, epoch, err);
+          else if (variant == 1) hipLaunchKernelGGL((k_persist<8, 16>), dim3(grid), dim3(256), 0, S, dstages, ns, xbuf, N, epoch, err);
+          else hipLaunchKernelGGL((k_persist<8, 64>), dim3(grid), dim3(256), 0, S, dstages, ns, xbuf, N, epoch, err);
+          CK(hipEventRecord(E1, S)); CK(hipEventSynchronize(E1));
+          float ms; CK(hipEventElapsedTime(&ms, E0, E1)); if (r > 0 && ms < best_b[variant]) best_b[variant] = ms;
+          epoch += (unsigned)ns + 1;
+        }
       int herr = 0; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
       size_t tot = 0; for (size_t b : set) tot += b;
-      printf("grid %4d  stages %2d  %-22s  kernel-chain %7.2f  persistent-tagged %7.2f  us/stage%s\n", grid, ns,
-             set.size() > 1 ? "layer 25|1|17|134|67 MB" : (std::to_string(set[0] / MB) + " MB").c_str(),
-             best_a * 1e3f / ns, best_b * 1e3f / ns, herr ? "   (SPIN TIMEOUT)" : "");
+      printf("grid %4d  stages %2d  %-22s  kernel-chain %7.2f  persistent-tagged (sleep 2/16/64) %7.2f %7.2f %7.2f  us/stage%s\n", grid, ns,
+             set.size() > 1 ? (set[0] == 25 * MB ? "layer 25|1|17|134|67 MB" : "layer 4|3|3|35|17 MB") : (std::to_string(set[0] / MB) + " MB").c_str(),
+             best_a * 1e3f / ns, best_b[0] * 1e3f / ns, best_b[1] * 1e3f / ns, best_b[2] * 1e3f / ns, herr ? "   (SPIN TIMEOUT)" : "");
       (void)tot;
       fflush(stdout);
     }
