@@ -334,6 +334,10 @@ _PF_SPECS = {
                                   binfmt.ROPE_HALF, 1000000.0, 1e-6, "pf-qwen"),
     "int8": binfmt.ModelSpec(512, 1408, 2, 4, 4, 500, 512, False, binfmt.FAMILY_LLAMA, True, 64,
                              binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "pf-int8"),
+    # head size 128 with the half-mode RoPE (Llama-3-8B-like heads): rotation partners 64 rows apart,
+    # i.e. four MFMA row tiles - the paired-tile QKV epilogue with four workgroups per head
+    "gqa-half-hs128": binfmt.ModelSpec(512, 1536, 2, 4, 2, 640, 512, True, binfmt.FAMILY_LLAMA, False, 64,
+                                       binfmt.ROPE_HALF, 500000.0, 1e-5, "pf-gqa-half-hs128"),
 }
 
 
