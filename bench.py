@@ -376,9 +376,11 @@ def main():
     ap.add_argument("--cpu-tokens", type=int, default=128)
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--prefill-secondary", action="store_true", default=True)
-    ap.add_argument("--others", default=None,
-                    help="comma-separated further BASELINE configs measured briefly into the same line "
-                         "(default on one GPU: qwen2.5-0.5b,tinyllama-1.1b,llama2-7b; '' = none)")
+    ap.add_argument("--others", default="",
+                    help="comma-separated further BASELINE configs measured briefly into the same line, e.g. "
+                         "qwen2.5-0.5b,tinyllama-1.1b,llama2-7b (opt-in: they launch the same kernel "
+                         "instantiations at other sizes, which would blur a rocprofv3 --stats average of "
+                         "the default command)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -415,8 +417,6 @@ def main():
             secondary = {"error": repr(e)}
 
     others = None
-    if args.others is None:
-        args.others = "qwen2.5-0.5b,tinyllama-1.1b,llama2-7b" if world == 1 else ""
     if args.others:
         others = {}
         torch.cuda.empty_cache()
