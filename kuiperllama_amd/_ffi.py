@@ -21,7 +21,7 @@ EXPORTS = [
     "kh_argmax_f32_host", "kh_softmax_f32", "kh_scale_f32", "kh_scale_sum_f32",
     "kh_model_create_from_file", "kh_model_create_from_host_image",
     "kh_model_create_from_device_weights", "kh_model_destroy", "kh_model_get_config",
-    "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv",
+    "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv", "kh_model_write_kv",
     "kh_spm_create_from_file", "kh_spm_create_from_memory", "kh_spm_destroy", "kh_spm_vocab_size",
     "kh_spm_bos_id", "kh_spm_eos_id", "kh_spm_unk_id", "kh_spm_encode", "kh_spm_decode",
     "kh_bpe_create_from_file", "kh_bpe_create_from_memory", "kh_bpe_destroy", "kh_bpe_vocab_size",
@@ -113,6 +113,7 @@ def lib() -> C.CDLL:
     L.kh_model_get_logits.argtypes = [_vp, _vp]
     L.kh_model_get_kv.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]
     L.kh_model_read_kv.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp]
+    L.kh_model_write_kv.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp]
     L.kh_model_generate.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),
                                     C.POINTER(_i32), C.POINTER(_f32)]
     L.kh_model_generate_until.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),

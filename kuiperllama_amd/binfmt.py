@@ -223,13 +223,19 @@ def quantize_q80_torch(w: torch.Tensor, group_size: int) -> Tuple[torch.Tensor, 
 
 
 def synth_image(spec: ModelSpec, seed: int = 1234, device: str | torch.device = "cpu",
-                norm_jitter: float = 0.05) -> torch.Tensor:
+                norm_jitter: float = 0.05, final_norm_std: Optional[float] = None) -> torch.Tensor:
     """Seeded random model of shape ``spec`` as a uint8 tensor holding the exact ``.bin``
     bytes (header included).  Init follows the reference's own Python model
     (tools/model.py:232-247): N(0, 0.02) for embeddings/linears, N(0, 0.02/sqrt(2L)) for
     wo and w3; Qwen2 biases N(0, 0.02).  Norm weights are 1 + N(0, norm_jitter) so that
     the norm-weight multiply is exercised.  freqs_cos/sin are written as the exporter
     does (the C++ reader skips them).
+
+    ``final_norm_std``: when given, the final norm weight is N(0, final_norm_std) instead (zero
+    mean).  With the init above a TIED classifier maps the residual stream - dominated by the
+    input token's embedding row - back onto that very token, so greedy decoding sits on a fixed
+    point (one id repeated); a signed final norm removes the self-match and the greedy sequence
+    wanders over the vocabulary (parity tests that must not be satisfied by a repeated token).
     """
     device = torch.device(device)
     ents, total = layout(spec)
@@ -267,6 +273,8 @@ def synth_image(spec: ModelSpec, seed: int = 1234, device: str | torch.device = 
             assert pending_scale is not None
             dst.copy_(pending_scale)
             pending_scale = None
+        elif base == "final_norm" and final_norm_std is not None:
+            dst.normal_(0.0, final_norm_std, generator=gen)
         elif base in ("att_norm", "ffn_norm", "final_norm"):
             dst.normal_(0.0, norm_jitter, generator=gen).add_(1.0)
         elif base == "freqs_cos" or base == "freqs_sin":

@@ -978,12 +978,26 @@ extern "C" int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache) 
 extern "C" int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows,
                                 float* h_k, float* h_v) {
   if (!m || !h_k || !h_v || layer < 0 || layer >= m->cfg.layer_num || row0 < 0 || nrows <= 0 ||
-      row0 + nrows > m->cfg.cache_len)
+      (int64_t)row0 + nrows > m->cfg.cache_len)
     return KH_ERR_INVALID_ARG;
   const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
   const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
   KH_CHECK_HIP(hipMemcpyAsync(h_k, m->kcache + off, nb, hipMemcpyDeviceToHost, m->stream));
   KH_CHECK_HIP(hipMemcpyAsync(h_v, m->vcache + off, nb, hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+
+extern "C" int kh_model_write_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows,
+                                 const float* h_k, const float* h_v) {
+  if (!m || !h_k || !h_v || layer < 0 || layer >= m->cfg.layer_num || row0 < 0 || nrows <= 0 ||
+      (int64_t)row0 + nrows > m->cfg.cache_len)
+    return KH_ERR_INVALID_ARG;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
+  const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
+  KH_CHECK_HIP(hipMemcpyAsync(m->kcache + off, h_k, nb, hipMemcpyHostToDevice, m->stream));
+  KH_CHECK_HIP(hipMemcpyAsync(m->vcache + off, h_v, nb, hipMemcpyHostToDevice, m->stream));
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   return KH_OK;
 }

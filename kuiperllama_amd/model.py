@@ -120,6 +120,14 @@ class KuiperModel:
                                                v.ctypes.data), "kh_model_read_kv")
         return k, v
 
+    def write_kv(self, layer: int, row0: int, k: np.ndarray, v: np.ndarray) -> None:
+        """Overwrite cache rows [row0, row0 + len(k)) of `layer` (rotated keys / raw values)."""
+        k = np.ascontiguousarray(k, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        assert k.shape == v.shape and k.ndim == 2 and k.shape[1] == self.cfg.kv_dim
+        _ffi.check(_ffi.lib().kh_model_write_kv(self._h, layer, row0, k.shape[0], k.ctypes.data,
+                                                v.ctypes.data), "kh_model_write_kv")
+
     # ---- demo/main.cpp generate() ---------------------------------------------------------
     def generate(self, prompt: Sequence[int], total_steps: int, exec: str = "graph",
                  stop: Optional[Sequence[int]] = None) -> Tuple[List[int], float]:

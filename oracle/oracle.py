@@ -284,7 +284,11 @@ class OracleModel:
             lib().ko_model_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def expected_bytes(self) -> int:
         return int(lib().ko_model_expected_bytes(self._h))

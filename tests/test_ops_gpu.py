@@ -419,6 +419,51 @@ def test_mha_decode_gqa_group_path(gpu, oracle, heads, kv_heads, hs, monkeypatch
     assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
 
 
+@pytest.mark.parametrize("layer_index", [15, 33])
+def test_mha_decode_real_stride_deep_layer(gpu, oracle, layer_index):
+    """Llama-3.2-1B attention geometry at the REAL cache stride (seq_len = 131072 rows per layer),
+    in a deep layer, with the DEFAULT path policy (no KH_ATTN_TLONG override): pos 4094 is the last
+    position of the per-head split path, 4095 the first of the GQA group path (pos + 1 >= 4096),
+    65535 / 131071 are deep into it and at the very last cache row.  layer 15 = the model's last
+    layer (element offset 1.0e9, byte offset past 2^31); layer 33 = an element offset past 2^31
+    (2.2e9: the int32 hazard the reference itself notes, model.cpp:226-243).  Only the addressed
+    layer holds data - every other row of the cache tensor is NaN, so an offset error cannot
+    pass.  Checked against the oracle's mha on that layer's slice (cpu/mha_kernel.cpp:10
+    layer_offset = layer_index * seq_len * kv_dim)."""
+    from kuiperllama_amd import ops
+    heads, kv_heads, hs, seq = 32, 8, 64, 131072
+    kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+    rng = np.random.default_rng(1000 + layer_index)
+    k_l = rng.standard_normal((seq, kv_dim), dtype=np.float32)
+    v_l = rng.standard_normal((seq, kv_dim), dtype=np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    k_l[70000, :hs] = 0.5 * q[:hs]           # one dominant key deep in the cache (kv group 0)
+    k_l[4095, hs:2 * hs] = 0.4 * q[4 * hs:5 * hs]  # and one exactly at the path switch (group 1)
+    kcd = torch.full((layer_index + 1, seq, kv_dim), float("nan"), device=gpu)
+    vcd = torch.full((layer_index + 1, seq, kv_dim), float("nan"), device=gpu)
+    kcd[layer_index].copy_(torch.from_numpy(k_l))
+    vcd[layer_index].copy_(torch.from_numpy(v_l))
+    qd = dev(q, gpu)
+    ws = ops.mha_decode_workspace(heads, hs, seq, gpu)
+    assert ws is not None and ws.numel() > 0
+    for pos in (4094, 4095, 4096, 65535, 131071):
+        out = torch.full((dim,), float("nan"), device=gpu)
+        ops.mha_decode(torch.tensor([pos], dtype=torch.int32, device=gpu), heads, layer_index, seq,
+                       kv_dim, kv_mul, hs, out, qd, kcd, vcd, ws)
+        # the oracle on the layer's slice (as layer 0 of a one-layer cache)
+        oo, _ = oracle.mha(pos, heads, 0, seq, kv_dim, kv_mul, hs, q, k_l[None], v_l[None],
+                           acc=oracle.ACC_F64)
+        got = host(out)
+        assert np.isfinite(got).all(), f"layer {layer_index} pos {pos}: read outside the layer"
+        np.testing.assert_allclose(got, oo, rtol=0, atol=3e-5,
+                                   err_msg=f"layer {layer_index} pos {pos}")
+    # the host-pos form of the same entry (d_pos == NULL) at the last row
+    out = torch.full((dim,), float("nan"), device=gpu)
+    ops.mha_decode(131071, heads, layer_index, seq, kv_dim, kv_mul, hs, out, qd, kcd, vcd, ws)
+    np.testing.assert_allclose(host(out), oo, rtol=0, atol=3e-5)
+    assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
+
+
 # ---------------------------------------------------------------- CPU-only helpers of the reference
 def test_softmax_scale_scalesum(gpu, oracle):
     from kuiperllama_amd import ops
