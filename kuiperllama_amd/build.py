@@ -120,3 +120,19 @@ def build_ref_binding() -> str | None:
     subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
                            "ref", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
     return REF_BINDING_BIN
+
+
+REF_LAYERS_BIN = os.path.normpath(os.path.join(_PKG, "..", "oracle", "_ref", "test_ref_layers"))
+
+
+def build_ref_layers() -> str | None:
+    """tests/cpp/test_ref_layers.cpp: the reference's OWN op::*Layer classes (op/{layer,matmul,
+    rmsnorm,rope,mha,swiglu,add,embedding}.cpp compiled where they lie) over
+    tests/cpp/kernels_interfaces_hip.cpp + libkuiper_hip.so (oracle/Makefile `ref_layers`).  Only
+    where the reference checkout exists; the binary lands in oracle/_ref/ and travels to the GPU box."""
+    if not os.path.isdir(os.path.join(REF_ROOT, "kuiper", "include")):
+        return REF_LAYERS_BIN if os.path.exists(REF_LAYERS_BIN) else None
+    build_lib()
+    subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
+                           "ref_layers", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
+    return REF_LAYERS_BIN

@@ -1,0 +1,85 @@
+// kernels_interfaces_hip.cpp — the reference's kernel::get_*_kernel getters
+// (kuiper/source/op/kernels/kernels_interfaces.cpp:21-132) with the HIP branch INTEGRATION.md §1
+// writes, compiled against the reference's OWN kernels_interface.h and linked under the reference's
+// OWN op::*Layer classes (oracle/Makefile target `ref_layers`): every
+//     kernel::get_matmul_kernel(device_type_)(get_input(0), get_weight(0), ...)
+// inside op::MatmulLayer::forward (op/matmul.cpp:57-80) and its seven siblings resolves HERE and
+// lands in libkuiper_hip.so.
+//
+// Device enumerator: INTEGRATION.md adds `kDeviceHIP = 3` to base::DeviceType (base/base.h:35-39).
+// The reference header cannot be edited from this repo, and the reference's allocator
+// (CUDADeviceAllocator, alloc_cu.cpp) stamps its buffers kDeviceCUDA - which in this test build hands
+// out MI355X memory (tests/cpp/ref_stubs/cuda_runtime_api.h forwards cudaMalloc to hipMalloc).  So
+// in this translation unit BOTH enumerators select the HIP kernels: kDeviceCUDA because that is the
+// device tag the reference's own tensors carry here, value 3 because that is what a maintainer adds.
+// The CPU branch is what the reference has and is not linked here (its cpu/*.cpp need a real
+// Armadillo + BLAS): asking for it is a loud error, never a silent fallback.
+#include "kernels_interface.h"  // the reference's: -I$KUIPER_REF/kuiper/source/op/kernels
+
+#include <glog/logging.h>
+
+#include "kuiper_hip_adapter.hpp"
+
+namespace kernel {
+namespace {
+using HipK = kuiper_hip::Kernels<tensor::Tensor, kernel::CudaConfig, base::DeviceType>;
+constexpr base::DeviceType kDeviceHIP = static_cast<base::DeviceType>(3);
+inline bool on_hip(base::DeviceType d) { return d == base::DeviceType::kDeviceCUDA || d == kDeviceHIP; }
+}  // namespace
+
+AddKernel get_add_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_add_kernel();
+  LOG(FATAL) << "Unknown device type for get a add kernel.";
+  return nullptr;
+}
+EmbeddingKernel get_emb_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_emb_kernel();
+  LOG(FATAL) << "Unknown device type for get an embedding kernel.";
+  return nullptr;
+}
+MatmulKernel get_matmul_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_matmul_kernel();
+  LOG(FATAL) << "Unknown device type for get an matmul kernel.";
+  return nullptr;
+}
+MatmulKernelQuant get_matmul_kernel_quant8(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_matmul_kernel_quant8();
+  LOG(FATAL) << "Unknown device type for get an matmul kernel.";
+  return nullptr;
+}
+MHAKernel get_mha_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_mha_kernel();
+  LOG(FATAL) << "Unknown device type for get an mha kernel.";
+  return nullptr;
+}
+RoPEKernel get_rope_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_rope_kernel();
+  LOG(FATAL) << "Unknown device type for get a rope kernel.";
+  return nullptr;
+}
+ScaleKernel get_scale_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_scale_kernel();
+  LOG(FATAL) << "Unknown device type for get a scale kernel.";
+  return nullptr;
+}
+SoftmaxInplaceKernel get_softmax_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_softmax_kernel();
+  LOG(FATAL) << "Unknown device type for get an softmax kernel.";
+  return nullptr;
+}
+SwigluKernel get_swiglu_kernel(base::DeviceType device_type, void* /*stream*/) {
+  if (on_hip(device_type)) return HipK::get_swiglu_kernel();
+  LOG(FATAL) << "Unknown device type for get a swiglu kernel.";
+  return nullptr;
+}
+RMSNormKernel get_rmsnorm_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_rmsnorm_kernel();
+  LOG(FATAL) << "Unknown device type for get an rmsnorm kernel.";
+  return nullptr;
+}
+ScaleSumKernel get_scale_sum_kernel(base::DeviceType device_type) {
+  if (on_hip(device_type)) return HipK::get_scale_sum_kernel();
+  LOG(FATAL) << "Unknown device type for get a scale and reduce kernel.";
+  return nullptr;
+}
+}  // namespace kernel
