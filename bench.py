@@ -24,6 +24,13 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 * cpu_baseline : the CPU oracle (oracle/, a port of the reference's CPU backend — the
              reference's C++ cannot be built here) timed on this host's cores on a bounded
              number of tokens of the same workload.
+* other_configs : the remaining BASELINE.json configs (Qwen2.5-0.5B, TinyLlama-1.1B = the
+             north-star floor of 60 tok/s, Llama-2-7B fp32 = one replica of config 5) measured
+             briefly into the same line, each with a token check against a short oracle pass.
+             --no-others for rocprofv3 runs (they launch the same kernel instantiations at other
+             sizes and would blur the --stats average of the headline workload).
+* long_context : single-step latency of the headline workload deep in its 131072-row cache.
+* --no-extras  : only the contract's timed region + the roofline kernel (smoke runs).
 """
 from __future__ import annotations
 
@@ -159,22 +166,55 @@ def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=1
            if variant == "openblas" else
            ("OpenMP row-parallel int8 group-dequant GEMV" if spec.quant else "OpenMP row-parallel fp32 GEMV"))
     return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "host": host_cpu_facts(),
             "sample": f"{n} decode steps = {passes} pass(es) over the first {len(words)} steps of the "
                       f"same greedy decode ({spec.name}, prompt {PROMPT}), {how}, {dt:.1f}s",
             "variant": variant, "calibration_ms_per_token": calib,
             "tokens_match_gpu": bool(match), "tokens_compared": n_cmp, "first_divergence": div}
 
 
+def host_cpu_facts() -> dict:
+    """What the CPU baseline ran on: logical CPUs the OS shows, the cgroup quota, and what the
+    process may really use (the baseline moves +-30 % between boxes with these)."""
+    from oracle import oracle as O
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if txt[0] == "max" else round(float(txt[0]) / float(txt[1]), 2)
+    except (OSError, ValueError, IndexError):
+        pass
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cgroup_cpu_quota": quota, "effective_cpus": O.effective_cpus(),
+            "cpu_model": model}
+
+
+TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
+
+
 def load_traffic(kernel_key):
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    """-> (HBM bytes per launch or None, provenance).  NOT measured in this run: PMC counters need
+    their own rocprofv3 passes (the guide's HBM section), so the figure is read from the committed
+    summary of those passes (tools/profile_pmc.sh -> tools/rocpd_summary.py); the provenance names
+    the file, the commit the counters were collected on and the correction applied."""
+    p = os.path.join(ROOT, TRAFFIC_FILE)
     try:
         with open(p) as f:
-            ent = json.load(f).get(kernel_key)
-            # HBM bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE x1024 x2 on gfx950
-            # + WRITE_SIZE x1024), summarised by tools/rocpd_summary.py
-            return float(ent["hbm_bytes"]) if ent else None
+            doc = json.load(f)
+        ent = doc.get(kernel_key)
+        meta = doc.get("_meta", {})
+        src = {"file": TRAFFIC_FILE, "measured_in_this_run": False,
+               "collected_on_commit": meta.get("commit"), "collected_by": meta.get("command"),
+               "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024"}
+        return (float(ent["hbm_bytes"]) if ent else None), src
     except Exception:
-        return None
+        return None, {"file": TRAFFIC_FILE, "measured_in_this_run": False, "error": "unreadable"}
 
 
 def host_mem_available_gb() -> float:
@@ -196,60 +236,101 @@ def host_mem_available_gb() -> float:
     return avail
 
 
-def cpu_extra_7b(spec_q8, img_q8_dev, local_rank, args):
+def cpu_int8_restated(spec_q8, img_q8_dev, args):
     """the reference has NO CPU int8 path (kernels_interfaces.cpp:54-61), so
-    the CPU comparison point for Llama-2-7B int8 is (i) CPU fp32 Llama-2-7B and (ii) the oracle's
-    own restated CPU int8 (cuda/matmul_kernel.cu:56-87 on the host), both clearly labelled."""
-    out = {}
-    dev = torch.device(f"cuda:{local_rank}")
-    half = max(4.0, args.cpu_budget_s / 3)
-    # (ii) restated CPU int8 on the very image the GPU ran
+    the CPU comparison points for Llama-2-7B int8 are (i) CPU fp32 Llama-2-7B - measured with the
+    fp32 image under other_configs.llama2-7b.cpu_baseline - and (ii) the oracle's own restated CPU
+    int8 (cuda/matmul_kernel.cu:56-87 on the host), measured here on the very image the GPU ran;
+    both clearly labelled."""
+    third = max(4.0, args.cpu_budget_s / 3)
     img_h = img_q8_dev.cpu().numpy()
     try:
-        r = cpu_baseline(spec_q8, img_h, [], 16, half, min_sample_s=half)
-        out["cpu_int8_restated"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant")}
-        out["cpu_int8_restated"]["label"] = ("oracle restatement of cuda/matmul_kernel.cu:56-87 on the "
-                                             "host; the reference itself has no CPU int8")
+        r = cpu_baseline(spec_q8, img_h, [], 16, third, min_sample_s=third)
     finally:
         del img_h
-    # (i) CPU fp32 Llama-2-7B: needs the 26.4 GB fp32 image on the host
-    s32 = binfmt.PRESETS["llama2-7b"]
-    need_gb = binfmt.image_nbytes(s32) / 1e9
-    have = host_mem_available_gb()
-    if have < need_gb + 8:
-        out["cpu_fp32"] = {"skipped": f"host memory {have:.0f} GB < {need_gb + 8:.0f} GB needed"}
-        return out
-    img32 = binfmt.synth_image(s32, seed=1234, device=dev)
-    torch.cuda.synchronize(dev)
-    img_h = img32.cpu().numpy()
-    del img32
-    torch.cuda.empty_cache()
-    try:
-        r = cpu_baseline(s32, img_h, [], 16, half, min_sample_s=half)
-        out["cpu_fp32"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant",
-                                             "calibration_ms_per_token")}
-        out["cpu_fp32"]["label"] = "reference-equivalent CPU fp32 path on Llama-2-7B (same shapes, fp32 weights)"
-    finally:
-        del img_h
-    return out
+    out = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant", "host")}
+    out["label"] = ("oracle restatement of cuda/matmul_kernel.cu:56-87 on the host; the reference itself "
+                    "has no CPU int8")
+    return {"cpu_int8_restated": out,
+            "cpu_fp32": {"see": "other_configs.llama2-7b.cpu_baseline (reference-equivalent CPU fp32 path on "
+                                "Llama-2-7B: same shapes, fp32 weights)"}}
 
 
-def quick_decode(spec, local_rank, steps=128):
-    """The other BASELINE configs in the same record (not the contract's timed region): 128 greedy
-    steps from pos 0, hipGraph replay, best of 3; tok/s and the whole-step fraction of 8 TB/s."""
+def other_config(spec, local_rank, args, steps=128):
+    """One of the remaining BASELINE configs in the same record (not the contract's timed region):
+    128 greedy steps from pos 0, hipGraph replay, best of 3 -> tok/s, ms per step, whole-step
+    fraction of 8 TB/s; then a bounded CPU-oracle pass over the same image for the token check
+    (common prefix with the GPU's words) and that config's CPU tok/s."""
     m, img = build_model(spec, local_rank)
     try:
         m.generate(PROMPT, 16, exec="graph")
-        ms = min(m.generate(PROMPT, steps, exec="graph")[1] for _ in range(3))
+        runs = [m.generate(PROMPT, steps, exec="graph") for _ in range(3)]
+        words, ms = min(runs, key=lambda r: r[1])
+        lat = {str(p): round(sorted(m.time_step(p, 5))[2], 2) for p in (0, 64, 127)}
     finally:
         m.close()
-        del img
-        torch.cuda.empty_cache()
     tok_s = steps / (ms * 1e-3)
     bytes_tok = spec.algorithmic_bytes_per_token((steps - 1) / 2.0)
-    return {"value": tok_s, "unit": "tokens/s", "ms_per_step": ms / steps,
-            "dtype": "int8 weights x f32 activations" if spec.quant else "f32",
-            "bytes_per_token": bytes_tok, "step_frac_of_8TBs": bytes_tok * tok_s / 8e12}
+    out = {"value": tok_s, "unit": "tokens/s", "ms_per_step": ms / steps, "steps": steps,
+           "dtype": "int8 weights x f32 activations" if spec.quant else "f32",
+           "bytes_per_token": bytes_tok, "step_frac_of_8TBs": bytes_tok * tok_s / 8e12,
+           "latency_us_at_pos": lat, "words_head": words[:8],
+           "tokens_match": None, "tokens_compared": 0}
+    if not args.no_cpu_baseline:
+        need_gb = binfmt.image_nbytes(spec) / 1e9
+        have = host_mem_available_gb()
+        if have < need_gb + 8:
+            out["cpu_baseline"] = {"skipped": f"host memory {have:.0f} GB < {need_gb + 8:.0f} GB needed"}
+        else:
+            big = need_gb > 8
+            budget = max(4.0, args.cpu_budget_s / 3) if big else 3.0
+            img_h = img.cpu().numpy()
+            try:
+                r = cpu_baseline(spec, img_h, words, 16 if big else 32, budget, min_sample_s=budget if big else 1.5)
+            finally:
+                del img_h
+            out["cpu_baseline"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant", "host")}
+            out["tokens_match"] = r["tokens_match_gpu"]
+            out["tokens_compared"] = r["tokens_compared"]
+            out["first_divergence"] = r["first_divergence"]
+    del img
+    torch.cuda.empty_cache()
+    return out
+
+
+LONG_POSITIONS = (4095, 4096, 32768, 131071)
+
+
+def long_context(m, spec, dev):
+    """Single-step latency of the graph-replayed decode step deep in the cache:
+    the K/V rows below the probed position are filled with random values on the GPU
+    (kh_model_write_kv takes device pointers too), then for each position the whole step
+    (kh_model_time_step, median of 9) and the attention kernel alone (back-to-back launches over
+    all layers).  attn_kv_frac = K/V bytes the position's attention must read
+    (L * 2 * (pos+1) * kv_dim * 4) / attention time of the L launches / 8 TB/s."""
+    cache_len = int(m.cfg.cache_len)
+    poss = [p for p in LONG_POSITIONS if p < cache_len]
+    if not poss:
+        return None
+    top = max(poss) + 1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    rows = 16384
+    for l in range(spec.n_layers):
+        for r0 in range(0, top, rows):
+            n = min(rows, top - r0)
+            kv = torch.empty((2, n, spec.kv_dim), dtype=torch.float32, device=dev).normal_(0.0, 1.0, generator=gen)
+            m.write_kv_device(l, r0, kv[0], kv[1])
+    torch.cuda.synchronize(dev)
+    out = {}
+    for p in poss:
+        us = sorted(m.time_step(p, 9))
+        attn_us = m.profile_kernel("attn", p, reps=4)
+        kv_bytes = 2.0 * (p + 1) * spec.kv_dim * 4
+        out[str(p)] = {"step_us": round(us[len(us) // 2], 2), "attn_us_per_layer": round(attn_us, 2),
+                       "attn_kv_bytes_per_layer": kv_bytes,
+                       "attn_kv_frac": kv_bytes / (attn_us * 1e-6) / (HBM_PEAK_GBS * 1e9)}
+    return out
 
 
 def measure(spec, args, rank, world, local_rank, primary):
@@ -269,29 +350,34 @@ def measure(spec, args, rank, world, local_rank, primary):
         "words_head": words[:8],
         "replicas": replicas.spread(per),
     }
-    # SURVEY 8d extras, all outside the contract's timed region: repeated runs (median) and the
-    # single-step latency at pos 0 / 64 / 127
-    reps = []
-    for _ in range(max(0, args.repeats - 1)):
-        _, ms = m.generate(PROMPT, args.steps, exec="graph")
-        reps.append(args.steps / (ms * 1e-3))
-    if reps:
-        allr = sorted(reps + [args.steps / (ev_ms * 1e-3)])
-        out["runs"] = {"n": len(allr), "median_tok_s": allr[len(allr) // 2], "min_tok_s": allr[0],
-                       "max_tok_s": allr[-1], "clock": "HIP events around the step loop, per replica"}
-    # the 128-step greedy run of the metric's definition (demo/main.cpp:69), untimed when --steps is
-    # smaller: source of the CPU token comparison and of the latency positions
-    ref_steps = max(args.steps, args.cpu_tokens, 128)
-    ref_words, ref_ms = (words, ev_ms) if ref_steps == args.steps else m.generate(PROMPT, ref_steps, exec="graph")
-    out["tok_s_128_steps"] = ref_steps / (ref_ms * 1e-3)
-    lat = {}
-    for p in (0, 64, 127):
-        us = sorted(m.time_step(p, 9))
-        lat[str(p)] = round(us[len(us) // 2], 2)
-    out["latency_us_at_pos"] = lat
+    ref_words = words
+    if args.extras:
+        # SURVEY 8d extras, all outside the contract's timed region: repeated runs (median) and the
+        # single-step latency at pos 0 / 64 / 127
+        reps = []
+        for _ in range(max(0, args.repeats - 1)):
+            _, ms = m.generate(PROMPT, args.steps, exec="graph")
+            reps.append(args.steps / (ms * 1e-3))
+        if reps:
+            allr = sorted(reps + [args.steps / (ev_ms * 1e-3)])
+            out["runs"] = {"n": len(allr), "median_tok_s": allr[len(allr) // 2], "min_tok_s": allr[0],
+                           "max_tok_s": allr[-1], "clock": "HIP events around the step loop, per replica"}
+        # the 128-step greedy run of the metric's definition (SURVEY 8d / demo/main.cpp:69), untimed by
+        # the contract when --steps is smaller: source of the CPU token comparison
+        ref_steps = max(args.steps, args.cpu_tokens, 128)
+        ref_words, ref_ms = (words, ev_ms) if ref_steps == args.steps else m.generate(PROMPT, ref_steps, exec="graph")
+        out["tok_s_128_steps"] = ref_steps / (ref_ms * 1e-3)
+        out["tok_s_128_steps_is"] = (f"the SURVEY 8(d) metric: {ref_steps} greedy steps from pos 0 (demo/main.cpp:69, "
+                                     "mean pos 63.5), HIP events around the step loop; `value` is the same loop over "
+                                     "--steps steps on the driver's clock")
+        lat = {}
+        for p in (0, 64, 127):
+            us = sorted(m.time_step(p, 9))
+            lat[str(p)] = round(us[len(us) // 2], 2)
+        out["latency_us_at_pos"] = lat
     # prompt phase (extends the reference): 128 fed-only prompt tokens, timed alone
     # with HIP events on the model stream (kh_model_time_prefill)
-    if primary or args.prefill_secondary:
+    if args.extras and (primary or args.prefill_secondary):
         rng = np.random.default_rng(0)
         pp = [int(t) for t in rng.integers(0, spec.vocab_size, 128)]
         pf = {}
@@ -324,34 +410,42 @@ def measure(spec, args, rank, world, local_rank, primary):
     # event between launches); "kernels_avg_us_evented" is the whole step with an event after
     # every kernel (adds ~3 us per kernel, kept as a cross-check of the launch sequence).
     ppos = min(args.steps - 1, 64)
-    prof = m.profile_step(start_pos=ppos, n_steps=8)
     b2b = m.profile_kernels(ppos, reps=8)
     k_us = b2b["ffn13"]
     kb = ffn13_bytes(spec)
     achieved = kb / (k_us * 1e-6) / 1e9
-    tr = load_traffic(f"{spec.name}:ffn13")
+    tr, tr_src = load_traffic(f"{spec.name}:ffn13")
     L = spec.n_layers
     out["roofline"] = {
         "bound": "hbm", "kernel": "k_ffn13 (w1,w3 GEMV + SwiGLU)", "achieved": achieved,
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": tr, "bytes_per_launch": kb, "avg_launch_us": k_us,
+        "traffic": tr, "traffic_source": tr_src, "bytes_per_launch": kb, "avg_launch_us": k_us,
         "step": {"achieved": out["step_gbs"], "frac": out["step_gbs"] / HBM_PEAK_GBS,
                  "bytes_per_token": bytes_tok},
         "kernels_avg_us": {n: round(v, 3) for n, v in b2b.items()},
         "kernels_sum_us_per_token": round(sum(v * (L if n not in ("cls", "sample") else 1)
                                               for n, v in b2b.items()), 1),
-        "kernels_avg_us_evented": {n: round(v["avg_us"], 3) for n, v in prof.items()},
     }
+    if args.extras:
+        prof = m.profile_step(start_pos=ppos, n_steps=8)
+        out["roofline"]["kernels_avg_us_evented"] = {n: round(v["avg_us"], 3) for n, v in prof.items()}
+        if primary and world == 1:
+            try:
+                lc = long_context(m, spec, dev)
+                if lc:
+                    out["long_context"] = lc
+            except Exception as e:  # noqa: BLE001  (the contract's numbers must still be reported)
+                out["long_context"] = {"error": repr(e)}
     m.close()
     del m
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.extras:
         if primary:
             img_h = img.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(spec, img_h, ref_words, args.cpu_tokens, args.cpu_budget_s)
             del img_h
         elif spec.name == "llama2-7b-int8":
             try:
-                out["cpu_baseline"] = cpu_extra_7b(spec, img, local_rank, args)
+                out["cpu_baseline"] = cpu_int8_restated(spec, img, args)
             except Exception as e:  # noqa: BLE001  (the GPU numbers must still be reported)
                 out["cpu_baseline"] = {"error": repr(e)}
     del img
@@ -359,7 +453,13 @@ def measure(spec, args, rank, world, local_rank, primary):
     return out
 
 
-def main():
+DEFAULT_OTHERS = "qwen2.5-0.5b,tinyllama-1.1b,llama2-7b"
+NORTH_STAR_FLOOR = {"config": "tinyllama-1.1b", "target_tok_s": 60.0,
+                    "source": "north_star: >= the reference's 60 tok/s on TinyLlama-1.1B fp32 "
+                              "(/root/reference/readme.md:25: 60.34 tok/s, RTX 3060 Laptop)"}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)  # generate(model, "a", 128), main.cpp:69
@@ -375,26 +475,39 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=128)
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
-    ap.add_argument("--prefill-secondary", action="store_true", default=True)
-    ap.add_argument("--others", default="",
-                    help="comma-separated further BASELINE configs measured briefly into the same line, e.g. "
-                         "qwen2.5-0.5b,tinyllama-1.1b,llama2-7b (opt-in: they launch the same kernel "
-                         "instantiations at other sizes, which would blur a rocprofv3 --stats average of "
-                         "the default command)")
-    args = ap.parse_args()
+    ap.add_argument("--prefill-secondary", action=argparse.BooleanOptionalAction, default=True,
+                    help="also time the prompt phase of the secondary workload")
+    ap.add_argument("--extras", action=argparse.BooleanOptionalAction, default=True,
+                    help="--no-extras: only the contract's timed region and the roofline kernel (no repeated "
+                         "runs, 128-step reference run, latency probes, prefill, long context, CPU baseline, "
+                         "other configs) - for smoke runs with a small --steps")
+    ap.add_argument("--others", default=None,
+                    help=f"comma-separated further BASELINE configs measured briefly into the same line "
+                         f"(default on one GPU: {DEFAULT_OTHERS}; '' or --no-others: none)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the other BASELINE configs (rocprofv3 runs: they launch the same kernel "
+                         "instantiations at other sizes and would blur the --stats average)")
+    args = ap.parse_args(argv)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     from kuiperllama_amd import replicas
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    rank, world, local_rank = replicas.init_from_env("nccl", torch.device(f"cuda:{local_rank}"))
+    # RCCL carries the timing protocol; KH_BENCH_DIST_BACKEND=gloo is the CPU test hook
+    # (tests/test_bench_main_gloo.py runs this function with world_size 2 and no GPU)
+    rank, world, local_rank = replicas.init_from_env(os.environ.get("KH_BENCH_DIST_BACKEND", "nccl"),
+                                                     torch.device(f"cuda:{local_rank}"))
     if world != args.gpus:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if args.workload is None:
         args.workload = replicas.default_workload(world)
     if args.secondary is None:
         args.secondary = "llama2-7b-int8" if world == 1 else ""
+    if args.others is None:
+        args.others = DEFAULT_OTHERS if world == 1 else ""
+    if args.no_others or not args.extras:
+        args.others = ""
 
     spec = binfmt.PRESETS[args.workload]
     res = measure(spec, args, rank, world, local_rank, primary=True)
@@ -422,7 +535,7 @@ def main():
         torch.cuda.empty_cache()
         for w in [x for x in args.others.split(",") if x and x not in (args.workload, args.secondary)]:
             try:
-                others[w] = quick_decode(binfmt.PRESETS[w], local_rank)
+                others[w] = other_config(binfmt.PRESETS[w], local_rank, args)
             except Exception as e:  # noqa: BLE001 - the contract's numbers must still be reported
                 others[w] = {"error": repr(e)}
 
@@ -445,15 +558,23 @@ def main():
             "roofline": res["roofline"],
             "replicas": res["replicas"],
             "runs": res.get("runs"), "tok_s_128_steps": res.get("tok_s_128_steps"),
+            "tok_s_128_steps_is": res.get("tok_s_128_steps_is"),
             "latency_us_at_pos": res.get("latency_us_at_pos"),
             "prefill": res.get("prefill"),
         }
+        if "long_context" in res:
+            line["long_context"] = res["long_context"]
         if "cpu_baseline" in res:
             line["cpu_baseline"] = res["cpu_baseline"]
         if secondary is not None:
             line["secondary"] = secondary
         if others:
             line["other_configs"] = others
+            fl = others.get(NORTH_STAR_FLOOR["config"])
+            if fl and "value" in fl:
+                line["north_star_floor"] = dict(NORTH_STAR_FLOOR, tok_s=fl["value"],
+                                                met=bool(fl["value"] >= NORTH_STAR_FLOOR["target_tok_s"]),
+                                                tokens_match=fl.get("tokens_match"))
         print(json.dumps(line), flush=True)
     replicas.shutdown(world)
 

@@ -209,9 +209,10 @@ int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache);
 /* copy rows [row0, row0+nrows) of one layer's K and V cache to host (tests) */
 int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows, float* h_k,
                      float* h_v);
-/* the inverse: overwrite rows [row0, row0+nrows) of one layer's K and V cache from host memory
- * (restoring a saved context; tests place known rows at deep positions without decoding up to
- * them).  Rows hold what the forward pass stores: RoPE-rotated keys, raw values. */
+/* the inverse: overwrite rows [row0, row0+nrows) of one layer's K and V cache from host memory or
+ * from memory of the model's device (restoring a saved context; tests and the long-context probes
+ * of bench.py place rows at deep positions without decoding up to them).  Rows hold what the
+ * forward pass stores: RoPE-rotated keys, raw values. */
 int kh_model_write_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows, const float* h_k,
                       const float* h_v);
 

@@ -537,6 +537,8 @@ int ensure_seq_cap(kh_model* m, int n) {
   int rc;
   if ((rc = dalloc(&m->d_forced, (size_t)n + 1)) != KH_OK) return rc;
   if ((rc = dalloc(&m->d_words, (size_t)n + 1)) != KH_OK) return rc;
+  // forced[i] = -1 (0xFFFFFFFF): every position sampled, until a generate uploads its prompt
+  KH_CHECK_HIP(hipMemsetAsync(m->d_forced, 0xFF, sizeof(int32_t) * ((size_t)n + 1), m->stream));
   m->seq_cap = n;
   // the graph captured pointers/capacity: rebuild
   if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
@@ -996,8 +998,9 @@ extern "C" int kh_model_write_kv(kh_model* m, int32_t layer, int32_t row0, int32
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
   const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
   const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
-  KH_CHECK_HIP(hipMemcpyAsync(m->kcache + off, h_k, nb, hipMemcpyHostToDevice, m->stream));
-  KH_CHECK_HIP(hipMemcpyAsync(m->vcache + off, h_v, nb, hipMemcpyHostToDevice, m->stream));
+  // hipMemcpyDefault: the source may be host memory or memory of this device (unified addressing)
+  KH_CHECK_HIP(hipMemcpyAsync(m->kcache + off, h_k, nb, hipMemcpyDefault, m->stream));
+  KH_CHECK_HIP(hipMemcpyAsync(m->vcache + off, h_v, nb, hipMemcpyDefault, m->stream));
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   return KH_OK;
 }
@@ -1750,9 +1753,13 @@ extern "C" int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos,
 
 extern "C" int kh_model_time_step(kh_model* m, int32_t pos, int32_t reps, float* h_us) {
   if (!m || !h_us || reps <= 0) return KH_ERR_INVALID_ARG;
-  if (pos < 0 || pos >= m->cfg.cache_len || pos >= m->seq_cap) return KH_ERR_RANGE;
-  if (!m->gexec) return KH_ERR_INVALID_ARG;  // a graph-mode generate must have run
+  if (pos < 0 || pos >= m->cfg.cache_len) return KH_ERR_RANGE;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  // deep positions (long-context probes): grow the forced/words buffers to cover `pos` and
+  // (re)capture the step graph if that replaced them
+  int rc;
+  if ((rc = ensure_seq_cap(m, pos + 1)) != KH_OK) return rc;
+  if ((rc = ensure_graph(m, m->seq_cap + 1)) != KH_OK) return rc;
   for (int r = 0; r < reps; ++r) {
     set_state(m, 1 % m->cfg.vocab_size, pos);
     KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));

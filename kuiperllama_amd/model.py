@@ -128,6 +128,15 @@ class KuiperModel:
         _ffi.check(_ffi.lib().kh_model_write_kv(self._h, layer, row0, k.shape[0], k.ctypes.data,
                                                 v.ctypes.data), "kh_model_write_kv")
 
+    def write_kv_device(self, layer: int, row0: int, k: torch.Tensor, v: torch.Tensor) -> None:
+        """write_kv from contiguous fp32 GPU tensors [nrows, kv_dim] on the model's device."""
+        assert k.is_cuda and v.is_cuda and k.dtype == v.dtype == torch.float32
+        assert k.is_contiguous() and v.is_contiguous() and k.shape == v.shape
+        assert k.dim() == 2 and k.shape[1] == self.cfg.kv_dim
+        torch.cuda.current_stream(k.device).synchronize()  # the copy runs on the model's own stream
+        _ffi.check(_ffi.lib().kh_model_write_kv(self._h, layer, row0, k.shape[0], k.data_ptr(),
+                                                v.data_ptr()), "kh_model_write_kv")
+
     # ---- demo/main.cpp generate() ---------------------------------------------------------
     def generate(self, prompt: Sequence[int], total_steps: int, exec: str = "graph",
                  stop: Optional[Sequence[int]] = None) -> Tuple[List[int], float]:
@@ -191,6 +200,14 @@ class KuiperModel:
                        "kh_model_profile_kernel")
             out[_ffi.lib().kh_kclass_name(i).decode()] = float(us.value)
         return out
+
+    def profile_kernel(self, name: str, pos: int, reps: int = 8) -> float:
+        """Back-to-back average launch duration (us) of ONE kernel class ("attn", "ffn13", ...)."""
+        names = [_ffi.lib().kh_kclass_name(i).decode() for i in range(_ffi.KH_NUM_KCLASS)]
+        us = C.c_float(0.0)
+        _ffi.check(_ffi.lib().kh_model_profile_kernel(self._h, names.index(name), pos, reps,
+                                                      C.byref(us)), "kh_model_profile_kernel")
+        return float(us.value)
 
     def profile_step(self, start_pos: int, n_steps: int):
         """Per-kernel-class average launch duration (us) of the fused step, HIP events."""
