@@ -183,19 +183,6 @@ __device__ __forceinline__ float fma4(f32x4 w, f32x4 x, float acc) {
 
 // 4 packed int8 (one dword) . 4 floats
 __device__ __forceinline__ float dot4_i8(int packed, f32x4 x, float acc) {
-#if defined(KH_EXP_NOCVT) && KH_EXP_NOCVT
-  return __builtin_fmaf(__builtin_bit_cast(float, packed), x.x + x.y + x.z + x.w, acc);
-#endif
-#if defined(KH_EXP_UBYTE) && KH_EXP_UBYTE
-  {  // ablation (wrong results): unsigned byte converts (v_cvt_f32_ubyteN) instead of the sign-extending ones
-    const unsigned u = (unsigned)packed ^ 0x80808080u;
-    acc = __builtin_fmaf((float)(u & 0xffu), x.x, acc);
-    acc = __builtin_fmaf((float)((u >> 8) & 0xffu), x.y, acc);
-    acc = __builtin_fmaf((float)((u >> 16) & 0xffu), x.z, acc);
-    acc = __builtin_fmaf((float)(u >> 24), x.w, acc);
-    return acc;
-  }
-#endif
   acc = __builtin_fmaf((float)(int8_t)(packed & 0xff), x.x, acc);
   acc = __builtin_fmaf((float)(int8_t)((packed >> 8) & 0xff), x.y, acc);
   acc = __builtin_fmaf((float)(int8_t)((packed >> 16) & 0xff), x.z, acc);

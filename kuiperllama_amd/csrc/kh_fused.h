@@ -171,9 +171,6 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_attn_generic(const KhAttnArgs a) 
                    a.out + (size_t)h * a.head_size, nullptr, (float*)smem_raw);
 }
 
-#ifndef KH_EXP_NOSTAGE
-#define KH_EXP_NOSTAGE 0  // ablation switch (tools/exp_int8.sh): skip the input staging of wo / w2
-#endif
 // ---------------------------------------------------------------------------------------------
 // y = W . v ; x += y      (wo and w2 with their residual adds, llama3.cpp:670-686, 710-719)
 struct KhGemvResArgs {
@@ -207,19 +204,8 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
   };
   gemv_pairs<QUANT, U, SPLIT>(
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
-      [&]() __attribute__((always_inline)) {
-#if !KH_EXP_NOSTAGE
-        st.issue();
-#endif
-      },
-      [&]() __attribute__((always_inline)) {
-#if KH_EXP_NOSTAGE
-        __syncthreads();  // ablation: x is never staged (wrong results; staging cost upper bound)
-#else
-        st.finish(xs, 0.f, red);
-#endif
-      },
-      epi);
+      [&]() __attribute__((always_inline)) { st.issue(); },
+      [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -45,127 +45,106 @@ struct RowsQ8 {
   const float* sc1;
 };
 
+// One 16-byte load per row per lane (u-th of the chunk) and its FMAs: the units of the rolling
+// refill in gemv_pairs (registers of slot u are re-requested right after slot u was consumed).
+template <int U>
+__device__ __forceinline__ void load_u(RegsF32<U>& r, const RowsF32& rows, int c0, int M4, int lane,
+                                       int u) {
+  const int idx = c0 + u * KH_WAVE + lane;
+  const int cidx = idx < M4 ? idx : 0;  // clamped address; masked in fma_u
+  r.v0[u] = ld_nt(rows.w0 + cidx);
+  r.v1[u] = ld_nt(rows.w1 + cidx);
+  // the loads of a slot stay together and slots stay in order: the machine scheduler otherwise
+  // regroups them (all scales first, then all weights, ...), and since vmcnt retires in order the
+  // wait for slot 0 then covers most of the tile.  The SAME issue order in the prologue and in
+  // the rolling loop also keeps the compiler's merged waitcnt state at the loop header exact.
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int U>
+__device__ __forceinline__ void fma_u(const RegsF32<U>& r, const f32x4* xs, int c0, int M4, int lane,
+                                      int u, float& a0, float& a1) {
+  // Lanes past the end of the column range read a clamped address (load_u) and multiply by a
+  // zeroed x instead of branching around the FMAs: straight-line code keeps the compiler's
+  // s_waitcnt placement exact (every exec-mask branch is a merge point where it turns conservative
+  // and waits for most of the tile), and "+ w * 0" leaves the sum bit-identical.
+  const int idx = c0 + u * KH_WAVE + lane;
+  const bool in = idx < M4;
+  f32x4 xv = xs[in ? idx : 0];
+  xv.x = in ? xv.x : 0.f;
+  xv.y = in ? xv.y : 0.f;
+  xv.z = in ? xv.z : 0.f;
+  xv.w = in ? xv.w : 0.f;
+  a0 = fma4(r.v0[u], xv, a0);
+  a1 = fma4(r.v1[u], xv, a1);
+}
 template <int U>
 __device__ __forceinline__ void load_chunk(RegsF32<U>& r, const RowsF32& rows, int c0, int M4,
                                            int lane) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int idx = c0 + u * KH_WAVE + lane;
-    const int cidx = idx < M4 ? idx : 0;  // clamped address; masked in fma_chunk
-    r.v0[u] = ld_nt(rows.w0 + cidx);
-    r.v1[u] = ld_nt(rows.w1 + cidx);
-  }
+  for (int u = 0; u < U; ++u) load_u<U>(r, rows, c0, M4, lane, u);
 }
 template <int U>
 __device__ __forceinline__ void fma_chunk(const RegsF32<U>& r, const f32x4* xs, int c0, int M4,
                                           int lane, float& a0, float& a1) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int idx = c0 + u * KH_WAVE + lane;
-    if (idx < M4) {
-      const f32x4 xv = xs[idx];
-      a0 = fma4(r.v0[u], xv, a0);
-      a1 = fma4(r.v1[u], xv, a1);
-    }
-  }
+  for (int u = 0; u < U; ++u) fma_u<U>(r, xs, c0, M4, lane, u, a0, a1);
 }
 
 // int8 group-quantised rows (tools/export.py:134-210: int8[K*M] then fp32 scales[K*M/g]).
 // A lane's dwordx4 = 16 weights of ONE group (group is a power of two >= 16 on this path), so
 // one scale per load; dequant factored per 16-weight run:
 //   sum_i x_i * s_g * w_i  ==  s_g * sum_i x_i * w_i      (reference: cuda/matmul_kernel.cu:73)
-// Experiment switches (tools/exp_int8.sh builds variants; defaults are the shipped path).
-#ifndef KH_SCALE_BPERM
-#define KH_SCALE_BPERM 0  // measured SLOWER than direct scale loads (7B int8: 511 -> 455 tok/s)
-#endif
-#ifndef KH_EXP_NOSCALE
-#define KH_EXP_NOSCALE 0  // skip scale loads (wrong results; upper bound for scale handling)
-#endif
-#ifndef KH_EXP_NOLDS
-#define KH_EXP_NOLDS 0    // skip the LDS reads of x (wrong results; LDS cost upper bound)
-#endif
-#ifndef KH_EXP_NOCVT
-#define KH_EXP_NOCVT 0    // skip int8->f32 conversion (wrong results; VALU cost upper bound)
-#endif
-// Scales: with the exporter's group size 64 (gshift == 6) the U <= 4 loads of a chunk span at most
-// 64 groups, so ONE coalesced dword load per lane fetches all of them (lane l holds the scale of
-// group c0/4 + l) and each lane picks its U scales with ds_bpermute (LDS crossbar, no memory
-// access) — instead of U more VMEM instructions per row, which doubled the vector-memory issue
-// count of the int8 kernels.  Other group sizes keep the direct per-load scale fetch.
+// Issue order per slot u: q0[u], q1[u], s0[u], s1[u].  vmcnt retires in order, so slot u can be
+// consumed as soon as ITS four loads are back; with all weight loads first and all scale loads
+// behind them (the round-1/2 order) the first FMA waited for the whole tile.
+// (Scale handling measured in r2, profiles/r2_int8_convert_ab.txt + tools/mb_scale.hip: the
+// per-load scale fetch costs exactly its bytes; one coalesced scale load + ds_bpermute was slower.)
+template <int U>
+__device__ __forceinline__ void load_u(RegsQ8<U>& r, const RowsQ8& rows, int gshift, int c0, int M16,
+                                       int lane, int u) {
+  const int idx = c0 + u * KH_WAVE + lane;
+  const int cidx = idx < M16 ? idx : 0;
+  r.q0[u] = ld_nt(rows.w0 + cidx);
+  r.q1[u] = ld_nt(rows.w1 + cidx);
+  const int gi = (cidx << 4) >> gshift;
+  r.g0[u] = rows.sc0[gi];
+  r.g1[u] = rows.sc1[gi];
+  __builtin_amdgcn_sched_barrier(0);  // see the fp32 load_u
+}
+template <int U>
+__device__ __forceinline__ void fma_u(const RegsQ8<U>& r, const f32x4* xs, int c0, int M16, int plane,
+                                      int lane, int u, float& a0, float& a1) {
+  const int idx = c0 + u * KH_WAVE + lane;
+  {
+    // out-of-range lanes: clamped addresses and a zeroed group scale (see the fp32 fma_u);
+    // the int8 dot itself is finite, so scale 0 contributes exactly +0
+    const bool in = idx < M16;
+    const int ci = in ? idx : 0;
+    const f32x4 x0 = xs[ci], x1 = xs[plane + ci], x2 = xs[2 * plane + ci], x3 = xs[3 * plane + ci];
+    float t0 = 0.f, t1 = 0.f;
+    t0 = dot4_i8(r.q0[u].x, x0, t0);
+    t0 = dot4_i8(r.q0[u].y, x1, t0);
+    t0 = dot4_i8(r.q0[u].z, x2, t0);
+    t0 = dot4_i8(r.q0[u].w, x3, t0);
+    t1 = dot4_i8(r.q1[u].x, x0, t1);
+    t1 = dot4_i8(r.q1[u].y, x1, t1);
+    t1 = dot4_i8(r.q1[u].z, x2, t1);
+    t1 = dot4_i8(r.q1[u].w, x3, t1);
+    a0 = __builtin_fmaf(in ? r.g0[u] : 0.f, t0, a0);
+    a1 = __builtin_fmaf(in ? r.g1[u] : 0.f, t1, a1);
+  }
+}
 template <int U>
 __device__ __forceinline__ void load_chunk(RegsQ8<U>& r, const RowsQ8& rows, int gshift, int c0,
                                            int M16, int lane) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int idx = c0 + u * KH_WAVE + lane;
-    const int cidx = idx < M16 ? idx : 0;
-    r.q0[u] = ld_nt(rows.w0 + cidx);
-    r.q1[u] = ld_nt(rows.w1 + cidx);
-  }
-  if (KH_SCALE_BPERM && gshift == 6 && U <= 4) {
-    const int ng = M16 >> 2;  // groups per row
-    int gi = (c0 >> 2) + lane;
-    gi = gi < ng ? gi : 0;
-    r.g0[0] = rows.sc0[gi];
-    r.g1[0] = rows.sc1[gi];
-  } else if (KH_EXP_NOSCALE) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) r.g0[u] = r.g1[u] = 1.f;
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = c0 + u * KH_WAVE + lane;
-      const int cidx = idx < M16 ? idx : 0;
-      const int gi = (cidx << 4) >> gshift;
-      r.g0[u] = rows.sc0[gi];
-      r.g1[u] = rows.sc1[gi];
-    }
-  }
+  for (int u = 0; u < U; ++u) load_u<U>(r, rows, gshift, c0, M16, lane, u);
 }
 template <int U>
 __device__ __forceinline__ void fma_chunk(const RegsQ8<U>& r, const f32x4* xs, int c0, int M16,
-                                          int plane, int gshift, int lane, float& a0, float& a1) {
-  float g0[U], g1[U];
-  if (KH_SCALE_BPERM && gshift == 6 && U <= 4) {
-    // c0 is a multiple of 4 on this path (chunks start at multiples of 64*U or of the split
-    // quantum, see gemv_pairs), so group(c0 + u*64 + lane) - c0/4 = u*16 + lane/4
-    const int raw0 = __builtin_bit_cast(int, r.g0[0]), raw1 = __builtin_bit_cast(int, r.g1[0]);
+                                          int plane, int lane, float& a0, float& a1) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int src = (((c0 & 3) + u * KH_WAVE + lane) >> 2) << 2;  // byte address = 4 * lane id
-      g0[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, raw0));
-      g1[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, raw1));
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      g0[u] = r.g0[u];
-      g1[u] = r.g1[u];
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int idx = c0 + u * KH_WAVE + lane;
-    if (idx < M16) {
-#if KH_EXP_NOLDS
-      const f32x4 x0 = {1.f, 2.f, 3.f, 4.f}, x1 = x0, x2 = x0, x3 = x0;
-#else
-      const f32x4 x0 = xs[idx], x1 = xs[plane + idx], x2 = xs[2 * plane + idx],
-                  x3 = xs[3 * plane + idx];
-#endif
-      float t0 = 0.f, t1 = 0.f;
-      t0 = dot4_i8(r.q0[u].x, x0, t0);
-      t0 = dot4_i8(r.q0[u].y, x1, t0);
-      t0 = dot4_i8(r.q0[u].z, x2, t0);
-      t0 = dot4_i8(r.q0[u].w, x3, t0);
-      t1 = dot4_i8(r.q1[u].x, x0, t1);
-      t1 = dot4_i8(r.q1[u].y, x1, t1);
-      t1 = dot4_i8(r.q1[u].z, x2, t1);
-      t1 = dot4_i8(r.q1[u].w, x3, t1);
-      a0 = __builtin_fmaf(g0[u], t0, a0);
-      a1 = __builtin_fmaf(g1[u], t1, a1);
-    }
-  }
+  for (int u = 0; u < U; ++u) fma_u<U>(r, xs, c0, M16, plane, lane, u, a0, a1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -192,6 +171,13 @@ struct Gemv<false, U> {
                                       float& a0, float& a1) const {
     fma_chunk<U>(r, xs, c0, lim, lane, a0, a1);
   }
+  __device__ __forceinline__ void load1(Regs& r, const Rows& rw, int c0, int lim, int lane, int u) const {
+    load_u<U>(r, rw, c0, lim, lane, u);
+  }
+  __device__ __forceinline__ void fma1(const Regs& r, const f32x4* xs, int c0, int lim, int lane, int u,
+                                       float& a0, float& a1) const {
+    fma_u<U>(r, xs, c0, lim, lane, u, a0, a1);
+  }
 };
 
 template <int U>
@@ -213,7 +199,14 @@ struct Gemv<true, U> {
   }
   __device__ __forceinline__ void fma(const Regs& r, const f32x4* xs, int c0, int lim, int lane,
                                       float& a0, float& a1) const {
-    fma_chunk<U>(r, xs, c0, lim, Mc + 1, gshift, lane, a0, a1);
+    fma_chunk<U>(r, xs, c0, lim, Mc + 1, lane, a0, a1);
+  }
+  __device__ __forceinline__ void load1(Regs& r, const Rows& rw, int c0, int lim, int lane, int u) const {
+    load_u<U>(r, rw, gshift, c0, lim, lane, u);
+  }
+  __device__ __forceinline__ void fma1(const Regs& r, const f32x4* xs, int c0, int lim, int lane, int u,
+                                       float& a0, float& a1) const {
+    fma_u<U>(r, xs, c0, lim, Mc + 1, lane, u, a0, a1);
   }
 };
 
@@ -244,8 +237,7 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
   // work-item arithmetic - pair index, row addresses, loop control - to the scalar unit: same-box A/B
   // (profiles/r2_scalar_wave_ab.txt) fp32 +0.6 % (cls 154 -> 151 us, qkv 6.5 -> 6.4), but the int8
   // kernels, whose loop is VALU-heavier, lose 0.7 % (ffn13 18.0 -> 18.4 us) - so fp32 only.
-  const int wave = QUANT ? (int)(threadIdx.x >> 6)
-                         : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int part = wave & (SPLIT - 1);
   const int gp = vb * PPW + wave / SPLIT;
   const int np = vgrid * PPW;
@@ -268,28 +260,18 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
   auto aux = PRE(p0);
   FINISH();
   const int iters = (total + np - 1) / np;  // uniform trip count: the SPLIT path has barriers
-  for (int it = 0; it < iters; ++it) {
-    const int p = gp + it * np;
-    const bool valid = p < total;  // uniform per wave
-    float a0 = 0.f, a1 = 0.f;
-    if (valid) {
-      for (int c0 = cb;;) {
-        g.fma(regs, xs, c0, ce, lane, a0, a1);
-        c0 += step;
-        if (c0 >= ce) break;
-        g.load(regs, cur, c0, ce, lane);
-      }
-    }
-    const int pn = p + np;
-    auto aux_next = aux;
-    if (pn < total) {  // next pair's first chunk is in flight during the reduction + epilogue
-      cur = PAIR(pn);
-      g.load(regs, cur, cb, ce, lane);
-      aux_next = PRE(pn);
-    }
+  // The tile registers ROLL: slot u of the next tile is requested right after slot u of the current
+  // tile was consumed, so (U-1)/U of a tile stays in flight while the wave computes - with "consume
+  // the whole tile, then request the next" (rounds 1-2) a wave had nothing in flight during its
+  // FMAs, 20 % of the int8 kernels' cycle (profiles/r3_rolling_refill_ab.txt).  One chunk covers a
+  // wave's column range in every BASELINE shape (pick_shape sizes U for it), so "next tile" is
+  // normally the wave's next row pair.
+  // reduction + epilogue of one work item (shared by the two loops below)
+  auto finish_item = [&](int p, bool valid, float a0, float a1, const decltype(aux)& ax)
+                         __attribute__((always_inline)) {
     float s0 = wave_sum(a0), s1 = wave_sum(a1);
     if constexpr (SPLIT == 1) {
-      if (valid) EPI(p, s0, s1, aux);
+      if (valid) EPI(p, s0, s1, ax);
     } else {
       if (lane == 0) {
         comb[2 * wave] = s0;
@@ -304,11 +286,47 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
           s0 += comb[2 * (wave + k)];
           s1 += comb[2 * (wave + k) + 1];
         }
-        EPI(p, s0, s1, aux);
+        EPI(p, s0, s1, ax);
       }
       __syncthreads();
     }
-    aux = aux_next;
+  };
+  // ONE loop over the wave's tiles (pair, chunk) in order, a single body that consumes slot u and
+  // re-requests it for the following tile - the next chunk of the same rows or the first chunk of
+  // the wave's next pair.  (A second loop body for multi-chunk rows next to a rolling one doubled
+  // the VGPR count - two tile register sets plus phi copies that drain vmcnt at every latch.)
+  // All control below is scalar (wave index is readfirstlane'd): s_cbranch_scc, no exec masking.
+  int p = gp, c0 = cb, it = 0;
+  float a0 = 0.f, a1 = 0.f;
+  for (;;) {
+    const bool valid = p < total;  // uniform per wave
+    const int c1 = c0 + step;
+    const bool last = c1 >= ce;    // last chunk of this wave's column range
+    const int pn = last ? p + np : p;
+    const int cn = last ? cb : c1;
+    const bool more = pn < total;  // the wave has a following tile (implies valid)
+    if (more) {
+      typename Gemv<QUANT, U>::Rows nxt = cur;
+      if (last) nxt = PAIR(pn);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        g.fma1(regs, xs, c0, ce, lane, u, a0, a1);
+        g.load1(regs, nxt, cn, ce, lane, u);
+      }
+      cur = nxt;
+    } else if (valid) {
+      g.fma(regs, xs, c0, ce, lane, a0, a1);
+    }
+    if (last) {
+      auto aux_next = aux;
+      if (more) aux_next = PRE(pn);  // epilogue operands of the next pair: requested behind its tile
+      finish_item(p, valid, a0, a1, aux);
+      aux = aux_next;
+      a0 = a1 = 0.f;
+      if (++it == iters) break;
+    }
+    p = pn;
+    c0 = cn;
   }
 }
 struct NoAux {};
@@ -356,8 +374,12 @@ __device__ __forceinline__ void stage_vec(const float* __restrict__ x,
 // norm weight) in flight, finish() reduces / normalises / writes LDS.  MAXV is a COMPILE-TIME
 // choice (straight-line code between the x loads and their use, otherwise the compiler's
 // waitcnt merge degrades to vmcnt(0) = "wait for the weights too"):
-//   MAXV = 4  vectors up to 4096 floats (dim of every BASELINE config)
-//   MAXV = 0  any length: single-phase stage_vec after the first weight loads were issued
+//   MAXV = 4  vectors up to 16 floats per thread (4096 at 256 threads: dim of every BASELINE config)
+//   MAXV = 6  up to 24 floats per thread (12288 at 512 threads: the 11008-float hidden vector of
+//             Llama-2-7B's w2; k_gemv_res only)
+//   MAXV = 0  any length: single-phase stage_vec AFTER the first weight loads were issued - its x
+//             loads sit behind the weight loads in the in-order vmcnt queue, so the staging (and
+//             everything after it) waits for the whole first tile
 template <bool NORM, bool LAYOUT_Q8, int MAXV>
 struct Stager {
   f32x4 xv[MAXV > 0 ? MAXV : 1];
@@ -415,4 +437,6 @@ struct Stager {
     }
   }
 };
-static inline int kh_stage_maxv(int M, int wg = KH_WG) { return M <= 4 * 4 * wg ? 4 : 0; }
+static inline int kh_stage_maxv(int M, int wg = KH_WG) {
+  return M <= 4 * 4 * wg ? 4 : (M <= 6 * 4 * wg ? 6 : 0);
+}

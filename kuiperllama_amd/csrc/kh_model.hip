@@ -203,6 +203,14 @@ int ilog2_exact(int v) {
     else                                                    \
       KH_SEL_SP4(KERNEL, Q, UU, 0, SP, __VA_ARGS__);        \
   } while (0)
+// k_gemv_res only: the 6-deep in-register staging for hidden-sized inputs (kh_stage_maxv)
+#define KH_SEL_MV4X(KERNEL, Q, UU, MV, SP, ...)             \
+  do {                                                      \
+    if ((MV) == 6)                                          \
+      KH_SEL_SP4(KERNEL, Q, UU, 6, SP, __VA_ARGS__);        \
+    else                                                    \
+      KH_SEL_MV4(KERNEL, Q, UU, MV, SP, __VA_ARGS__);       \
+  } while (0)
 #define KH_SEL_U(SEL, KERNEL, QUANT, U, ...)                \
   do {                                                      \
     if (QUANT) {                                            \
@@ -224,6 +232,8 @@ int ilog2_exact(int v) {
   KH_SEL_U(KH_SEL_MV3, KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS)
 #define KH_DISPATCH4(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
   KH_SEL_U(KH_SEL_MV4, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
+#define KH_DISPATCH4X(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV4X, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
 
 KhQkvArgs fill_qkv(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -340,8 +350,8 @@ void launch_w2(kh_model* m, int l) {
   a.gshift = m->gshift;
   const bool qn = c.is_quant;
   const int kh_launch_wg = m->sh_w2.wg;
-  KH_DISPATCH4(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split, m->sh_w2.grid,
-               fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
+  KH_DISPATCH4X(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split, m->sh_w2.grid,
+                fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
 }
 void launch_cls(kh_model* m) {
   const kh_config& c = m->cfg;
@@ -793,6 +803,8 @@ int finish_create(kh_model* m) {
     const int v = (int)lds_need;
 #define KH_ATTR(Q, UU, SP)                                                                     \
   (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP>,                             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, v);                    \
+  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 6, SP>,                             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, v)
     KH_ATTR(false, 8, 1); KH_ATTR(false, 8, 2); KH_ATTR(false, 8, 4);
     KH_ATTR(false, 4, 1); KH_ATTR(false, 4, 2); KH_ATTR(false, 4, 4);

@@ -82,7 +82,6 @@ template <int U, int B>
 __device__ __forceinline__ void fma_chunk_b(const RegsQ8<U>& r, const f32x4* xs, int xstride,
                                             int c0, int M16, int plane, int lane, float (&a0)[B],
                                             float (&a1)[B]) {
-  static_assert(!KH_SCALE_BPERM, "prefill uses the direct per-load scales");
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int idx = c0 + u * KH_WAVE + lane;
