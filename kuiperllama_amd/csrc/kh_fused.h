@@ -154,7 +154,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
     dst[r0] = s0;
     dst[r1] = s1;
   };
-  gemv_pairs<QUANT, U, SPLIT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre,
+  gemv_pairs<SPLIT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre,
                               [&]() __attribute__((always_inline)) { st.issue(); },
                               [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi);
 }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
     x[2 * p] = r.x0 + s0;
     x[2 * p + 1] = r.x1 + s1;
   };
-  gemv_pairs<QUANT, U, SPLIT>(
+  gemv_pairs<SPLIT>(
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
   auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane == 0) a.h[r] = swiglu1(s0, s1);
   };
-  gemv_pairs<QUANT, U, 1>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<1>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
                        [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
 }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
       amax_merge(bv, bi, s1, r1);
     }
   };
-  gemv_pairs<QUANT, U, 1>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
+  gemv_pairs<1>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
                           [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
                        [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);

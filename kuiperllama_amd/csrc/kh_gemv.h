@@ -154,6 +154,7 @@ struct Gemv;
 
 template <int U>
 struct Gemv<false, U> {
+  static constexpr int kU = U;
   using Regs = RegsF32<U>;
   using Rows = RowsF32;
   int Mc;  // chunks per row in 16-byte units: M/4
@@ -182,6 +183,7 @@ struct Gemv<false, U> {
 
 template <int U>
 struct Gemv<true, U> {
+  static constexpr int kU = U;
   using Regs = RegsQ8<U>;
   using Rows = RowsQ8;
   int Mc;  // M/16
@@ -225,11 +227,19 @@ struct Gemv<true, U> {
 // columns; partial sums are combined through LDS in fixed order (deterministic).  Used when a
 // matrix has too few rows to put >= ~4096 waves in flight (w2: 1024 pairs of 32 KiB rows), where
 // one wave per pair leaves 4 waves per CU and no load/compute overlap.  comb = LDS float[8].
-template <bool QUANT, int U, int SPLIT, class PairFn, class PreFn, class IssueFn, class FinishFn,
-          class EpiFn>
-__device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4* xs, int total,
-                                           int lane, float* comb, PairFn&& PAIR, PreFn&& PRE,
-                                           IssueFn&& ISSUE, FinishFn&& FINISH, EpiFn&& EPI) {
+// G: the matrix view - Gemv<QUANT, U>, or any class with its interface (kU, Regs, Rows, Mc, load,
+// load1, fma, fma1; tools/mb_gemv_ladder.hip plugs in stream-only views to price each ingredient).
+// DEPTH (1 or 2): register tiles a wave keeps in flight.  2 = the tiles of the wave's first TWO work
+// items are requested in the prologue (twice the bytes in flight while the input vector is staged,
+// and for matrices with <= 2 items per wave - wo, w2 - everything is in flight from the start);
+// needs one chunk per column range (host-checked).  ROLL: slot-by-slot refill (see below) or
+// "consume the tile, then request the next".
+template <int SPLIT, int DEPTH = 1, bool ROLL = true, class G, class PairFn, class PreFn, class IssueFn,
+          class FinishFn, class EpiFn>
+__device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int total, int lane,
+                                           float* comb, PairFn&& PAIR, PreFn&& PRE, IssueFn&& ISSUE,
+                                           FinishFn&& FINISH, EpiFn&& EPI) {
+  constexpr int U = G::kU;
   const int vb = (int)blockIdx.x, vgrid = (int)gridDim.x;
   static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
   const int PPW = kh_nwaves() / SPLIT;  // pairs per workgroup per iteration
@@ -247,17 +257,24 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
   const int cb = part * Q;
   const int ce = cb + Q < g.Mc ? cb + Q : g.Mc;
   const int p0 = gp < total ? gp : 0;
-  typename Gemv<QUANT, U>::Regs regs;
+  typename G::Regs regs;
   // the x loads leave FIRST - before the work-item decode of PAIR (k_qkv: an integer division and
   // three-way selects, ~80 instructions the compiler otherwise hoists above them)
   ISSUE();
   __builtin_amdgcn_sched_barrier(0);  // keep the x loads ahead of everything else, the weight loads included
-  typename Gemv<QUANT, U>::Rows cur = PAIR(p0);
+  typename G::Rows cur = PAIR(p0);
   // unconditional (an idle wave re-reads pair 0): a branch here would make the compiler merge
   // the vmcnt state of both paths and wait vmcnt(0) — i.e. for the weights — before using x.
   // The loads stay in flight across the staging barriers.
   g.load(regs, cur, cb, ce, lane);
   auto aux = PRE(p0);
+  typename G::Regs regs_b;  // second ring slot (DEPTH == 2)
+  auto aux_b = aux;
+  if constexpr (DEPTH == 2) {
+    const int p1 = gp + np < total ? gp + np : p0;
+    g.load(regs_b, PAIR(p1), cb, ce, lane);
+    aux_b = PRE(p1);
+  }
   FINISH();
   const int iters = (total + np - 1) / np;  // uniform trip count: the SPLIT path has barriers
   // The tile registers ROLL: slot u of the next tile is requested right after slot u of the current
@@ -291,6 +308,38 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
       __syncthreads();
     }
   };
+  if constexpr (DEPTH == 2) {
+    // work item p lives in ring slot r; consuming it re-requests the slot for item p + 2*np
+    auto item = [&](typename G::Regs& r, decltype(aux)& ax, int p) __attribute__((always_inline)) {
+      const bool valid = p < total;
+      const int pn = p + 2 * np;
+      float a0 = 0.f, a1 = 0.f;
+      auto ax_next = ax;
+      if (pn < total) {
+        const typename G::Rows nxt = PAIR(pn);
+        if constexpr (ROLL) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            g.fma1(r, xs, cb, ce, lane, u, a0, a1);
+            g.load1(r, nxt, cb, ce, lane, u);
+          }
+        } else {
+          g.fma(r, xs, cb, ce, lane, a0, a1);
+          g.load(r, nxt, cb, ce, lane);
+        }
+        ax_next = PRE(pn);
+      } else if (valid) {
+        g.fma(r, xs, cb, ce, lane, a0, a1);
+      }
+      finish_item(p, valid, a0, a1, ax);
+      ax = ax_next;
+    };
+    for (int it = 0; it < iters; it += 2) {
+      item(regs, aux, gp + it * np);
+      if (it + 1 < iters) item(regs_b, aux_b, gp + (it + 1) * np);
+    }
+    return;
+  }
   // ONE loop over the wave's tiles (pair, chunk) in order, a single body that consumes slot u and
   // re-requests it for the following tile - the next chunk of the same rows or the first chunk of
   // the wave's next pair.  (A second loop body for multi-chunk rows next to a rolling one doubled
@@ -306,12 +355,17 @@ __device__ __forceinline__ void gemv_pairs(const Gemv<QUANT, U>& g, const f32x4*
     const int cn = last ? cb : c1;
     const bool more = pn < total;  // the wave has a following tile (implies valid)
     if (more) {
-      typename Gemv<QUANT, U>::Rows nxt = cur;
+      typename G::Rows nxt = cur;
       if (last) nxt = PAIR(pn);
+      if constexpr (ROLL) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        g.fma1(regs, xs, c0, ce, lane, u, a0, a1);
-        g.load1(regs, nxt, cn, ce, lane, u);
+        for (int u = 0; u < U; ++u) {
+          g.fma1(regs, xs, c0, ce, lane, u, a0, a1);
+          g.load1(regs, nxt, cn, ce, lane, u);
+        }
+      } else {
+        g.fma(regs, xs, c0, ce, lane, a0, a1);
+        g.load(regs, nxt, cn, ce, lane);
       }
       cur = nxt;
     } else if (valid) {

@@ -117,14 +117,20 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
   const int elem = quant ? 1 : 4;
   const int min_bytes = quant ? 4096 : 8192;  // bytes one wave must still stream per pair
   const long pair_bytes = 2L * M * elem;
-  const int target_waves = pair_bytes >= 16384 ? 8192 : 4096;
+  // waves to aim for before rows are split.  With the rolling tile refill a wave that walks several
+  // chunks of a long row keeps its loads in flight, so fewer, longer-lived waves beat many short
+  // ones (r3 sweeps, profiles/r3_shape_sweep.md: Llama-2-7B w2 int8 split 4 -> 2: 12.6 -> 10.8 us,
+  // fp32 33.6 -> 31.4; wo int8 split 2 -> 1: 5.6 -> 5.25); rounds 1-2 aimed at twice as many.
+  const int target_waves = pair_bytes >= 16384 ? 4096 : 2048;
   while (sh.split < max_split && pairs * sh.split < target_waves &&
          pair_bytes / (sh.split * 2) >= min_bytes)
     sh.split *= 2;
   const int Mc = quant ? M / 16 : M / 4;
   const int per_lane = ((Mc + sh.split - 1) / sh.split + KH_WAVE - 1) / KH_WAVE;
   if (quant)
-    sh.u = per_lane >= 3 ? 4 : 2;
+    // one chunk when it covers the column range; ranges that need several chunks anyway take the
+    // small one (less padding in the last chunk, finer refill: w2 int8 u4 -> u2 11.9 -> 10.8 us)
+    sh.u = per_lane > 4 ? 2 : (per_lane >= 3 ? 4 : 2);
   else
     sh.u = per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
   const int ppw = (wg / KH_WAVE) / sh.split;  // pairs per workgroup per iteration
@@ -747,6 +753,12 @@ int finish_create(kh_model* m) {
   m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS",
                          c.is_quant ? KH_WG : KH_WG_MAX, KH_WG_MAX);
   m->nparts = m->sh_cls.grid;
+  if (getenv("KH_SHAPE_DEBUG")) {
+    const struct { const char* n; const kh_model::Shape* s; } all[] = {
+        {"qkv", &m->sh_qkv}, {"wo", &m->sh_wo}, {"ffn13", &m->sh_ffn}, {"w2", &m->sh_w2}, {"cls", &m->sh_cls}};
+    for (const auto& e : all)
+      fprintf(stderr, "[kh] shape %-5s split %d u %d grid %d wg %d\n", e.n, e.s->split, e.s->u, e.s->grid, e.s->wg);
+  }
   m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
   // attention: 8 waves per (head, split) shorten each lane's timestep loop
   m->attn_wg = KH_WG_MAX;

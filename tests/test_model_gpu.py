@@ -331,7 +331,8 @@ def test_full_size_baseline_shapes(gpu, oracle, preset, steps, n_tf):
     (a) greedy token ids identical from prompt [1, 263] (fp32: token for token; int8: on the
         seeded model), on a sequence that is NOT a fixed point (>= 20 distinct ids in 128 steps);
     (b) the LOGITS of the greedy run at four positions (second, quarter, half, last step) within
-        4e-5 (fp32) / 1e-4 (int8) of the oracle's;
+        4e-5 (fp32) / 1e-4 (int8) of the oracle's (Llama-2-7B fp32, 32 layers x dim 4096: at most 3x
+        as far from the fp64-accumulated gold as the fp32 oracle itself is);
     (c) a teacher-forced leg: n_tf random token ids through predict() and through the oracle's
         forward, logits compared at EVERY step (a tied model cannot hide on a fixed point, and an
         error far below the top-2 margin cannot hide behind equal argmaxes);
@@ -369,16 +370,32 @@ def test_full_size_baseline_shapes(gpu, oracle, preset, steps, n_tf):
     torch.cuda.empty_cache()
 
     om = oracle.OracleModel.from_spec(img_h, spec, cache_len=256)
+    # 32 layers x dim 4096 in fp32: the two fp32 paths (HIP, oracle) each sit a few 1e-5 from the
+    # exact result, so for the deep fp32 model the bound is stated against the fp64-accumulated
+    # gold run in lockstep: the HIP logits may be at most 3x as far from it as the fp32 oracle is
+    # (the criterion test_gemm_prefill_full_size uses), or within the absolute tolerance
+    gold = (oracle.OracleModel.from_spec(img_h, spec, cache_len=256)
+            if (not spec.quant and spec.n_layers >= 32) else None)
+
+    def bound(lo, tok, p):
+        if gold is None:
+            return atol, ""
+        lg64 = gold.forward(tok, p, oracle.ACC_F64)
+        e_orc = float(np.abs(lo - lg64).max())
+        return max(atol, 3.0 * e_orc + 1e-6), f" (|oracle32 - gold64| {e_orc:.2e})"
+
     want, worst = [], 0.0
     for p in range(steps):
-        lo = om.forward(_fed(prompt, want, p), p)
+        tok = _fed(prompt, want, p)
+        lo = om.forward(tok, p)
         want.append(prompt[p + 1] if p < len(prompt) - 1 else int(np.argmax(lo)))
         if want[p] != g[p]:
             _fail_with_margin(oracle, img_h, spec, prompt, g[:steps], want, cache_len=256)
+        lim, note = bound(lo, tok, p)
         if p in lg_gpu:
             err = float(np.abs(lg_gpu[p] - lo).max())
             worst = max(worst, err)
-            assert err <= atol, f"{preset}: greedy-run logits at pos {p} differ by {err:.3e} (> {atol})"
+            assert err <= lim, f"{preset}: greedy-run logits at pos {p} differ by {err:.3e} (> {lim:.2e}){note}"
     distinct = len(set(want))
     assert distinct >= min(20, steps // 2), f"{preset}: degenerate greedy sequence ({distinct} distinct ids)"
     worst_tf = 0.0
@@ -387,7 +404,8 @@ def test_full_size_baseline_shapes(gpu, oracle, preset, steps, n_tf):
         nxt, lg = tf_gpu[p]
         err = float(np.abs(lg - lo).max())
         worst_tf = max(worst_tf, err)
-        assert err <= atol, f"{preset}: teacher-forced logits at pos {p} differ by {err:.3e} (> {atol})"
+        lim, note = bound(lo, t, p)
+        assert err <= lim, f"{preset}: teacher-forced logits at pos {p} differ by {err:.3e} (> {lim:.2e}){note}"
         top2 = np.sort(lo)[-2:]
         if top2[1] - top2[0] > 2 * atol:
             assert nxt == int(np.argmax(lo)), (preset, p)
