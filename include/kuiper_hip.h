@@ -64,9 +64,10 @@ int kh_matmul_q8(const float* x, const int8_t* w8, const float* scales, int32_t 
                  float* y, int32_t M, int32_t K, void* stream);
 
 /* EmbeddingKernel (kernels_interface.h:16-17; cuda/emb_kernel.cu:3-48):
- * out[t,:] = W[tokens[t],:].  tokens is a DEVICE int32 array (the reference uploads a host
- * tensor per call, emb_kernel.cu:25-29; the host adapter does that upload).  Rows whose
- * token is outside [0, vocab) are left untouched. */
+ * out[t,:] = W[tokens[t],:].  tokens is a DEVICE int32 array (for callers that already hold the
+ * ids on the device; the reference hands over a HOST tensor and uploads it per call,
+ * emb_kernel.cu:25-29 - that form is kh_embedding_f32_host below, which the adapter uses).  Rows
+ * whose token is outside [0, vocab) are left untouched. */
 int kh_embedding_f32(const int32_t* tokens, int32_t n_tokens, const float* w, float* out,
                      int32_t dim, int32_t vocab, void* stream);
 
@@ -246,8 +247,10 @@ int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t po
  * tokens share one pass over the weights (v_mfma_f32_16x16x4_f32, exact fp32 arithmetic, tokens on
  * the MFMA N dimension; int8 weights dequantised per element in registers).  The K/V rows agree
  * with the token-by-token path to fp32 round-off (different summation order), not bit for bit.
- * kh_model_generate* use it for prompts with >= 16 fed-only tokens (env KH_PREFILL = 0 | gemv |
- * gemm overrides).  KH_ERR_UNSUPPORTED: head_size <= 32, dim/hidden not a multiple of 16 (fp32) /
+ * kh_model_generate* use it for prompts with >= 16 fed-only tokens - so for such prompts the greedy
+ * tokens carry this tolerance too and can differ from the token-by-token prompt phase at near-ties;
+ * env KH_PREFILL = 0 | token | gemv | gemm overrides (gemv = the bit-identical path; any other
+ * value makes generate return KH_ERR_INVALID_ARG).  KH_ERR_UNSUPPORTED: head_size <= 32, dim/hidden not a multiple of 16 (fp32) /
  * 64 (int8), int8 group size != 64. */
 int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
 

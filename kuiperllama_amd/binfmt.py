@@ -12,7 +12,7 @@ Host-side mirror of the reference's loader for the decode path:
   ``tools/export.py:134-210`` ("legacy_export_quant", version 3); quantiser
   ``tools/export.py:49-73``
 
-The C++ loader in ``csrc/kh_model.hip`` implements the same table; tests check the two
+The C++ loader in ``csrc/kh_model_load.hip`` implements the same table; tests check the two
 against each other and (in the build container only) against files written by the
 reference's own exporter.  No reference code is imported here.
 

@@ -572,7 +572,7 @@ __device__ __forceinline__ void attn_group_decode(const float* q_g, const float*
 }
 
 // =============================================================================================
-// The decode-attention launch shared by the fused step (kh_model.hip) and the operator-level
+// The decode-attention launch shared by the fused step (kh_model_step.hip) and the operator-level
 // entry point kh_mha_decode_f32 (kh_ops.hip).
 struct KhAttnArgs {
   const float* q;          // [dim]

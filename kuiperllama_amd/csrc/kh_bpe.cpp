@@ -180,13 +180,21 @@ struct Json {
     return true;
   }
   bool integer(long* v) {
+    // digits parsed by hand, bounded by `end`: the buffer (kh_bpe_create_from_memory's ptr/nbytes)
+    // is not NUL-terminated, so strtol could read past a file that is truncated inside a number
     ws();
-    char* e = nullptr;
-    const long x = strtol(p, &e, 10);
-    if (e == p) return ok = false;
+    const char* q = p;
+    bool neg = false;
+    if (q < end && (*q == '-' || *q == '+')) neg = *q++ == '-';
+    if (q >= end || *q < '0' || *q > '9') return ok = false;
+    long x = 0;
+    while (q < end && *q >= '0' && *q <= '9') {
+      if (x > (0x7fffffffL - 9) / 10) return ok = false;  // ids are int32
+      x = x * 10 + (*q++ - '0');
+    }
     // a fraction / exponent would not be an id
-    p = e;
-    if (v) *v = x;
+    p = q;
+    if (v) *v = neg ? -x : x;
     return true;
   }
   bool skip() {  // any value

@@ -213,6 +213,13 @@ __device__ __forceinline__ void wave_amax(float& v, int& i) {
   }
 }
 
+// weights of one projection, fp32 or int8+scales (file order of the .bin: int8[K*M] then scales)
+struct KhLin {
+  const void* w;        // fp32 [K,M] or int8 [K,M]
+  const float* scales;  // int8 only: [K*M/group]
+  const float* bias;    // Qwen2 q/k/v only
+};
+
 // ---- LDS layout of the activation vector for the int8 GEMV --------------------------------
 // A lane owns 16 consecutive weights (one dwordx4), so it needs 16 consecutive x values =
 // four float4 (f = 4j+i, i<4) per 16-chunk j.  Stored as slot(f) = (f&3)*(M16+1) + (f>>2):

@@ -22,12 +22,6 @@
 #include "kh_common.h"
 #include "kh_gemv.h"
 
-// weights of one projection, fp32 or int8+scales
-struct KhLin {
-  const void* w;        // fp32 [K,M] or int8 [K,M]
-  const float* scales;  // int8 only: [K*M/group]
-  const float* bias;    // Qwen2 q/k/v only
-};
 
 template <bool QUANT>
 __device__ __forceinline__ float* lds_red_ptr(f32x4* xs, int M) {
@@ -161,7 +155,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // head_size <= 32 (tiny test models): the generic LDS-score core of the op-level kernel
-__global__ __launch_bounds__(KH_WG_MAX) void k_attn_generic(const KhAttnArgs a) {
+static __global__ __launch_bounds__(KH_WG_MAX) void k_attn_generic(const KhAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int pos = *a.d_pos;
   const int h = blockIdx.x;
@@ -310,7 +304,7 @@ struct KhSampleArgs {
   int dim, vocab;
   int advance;            // 1: generate loop (feed next token, ++pos); 0: predict() only
 };
-__global__ __launch_bounds__(KH_WG) void k_sample(const KhSampleArgs a) {
+static __global__ __launch_bounds__(KH_WG) void k_sample(const KhSampleArgs a) {
   __shared__ float sv[KH_WAVES_PER_WG];
   __shared__ int si[KH_WAVES_PER_WG];
   __shared__ int s_next;
@@ -354,7 +348,7 @@ __global__ __launch_bounds__(KH_WG) void k_sample(const KhSampleArgs a) {
 }
 
 // set (token, pos) from the host and gather the embedding row: start of generate / predict
-__global__ __launch_bounds__(KH_WG) void k_set_state(int token, int pos, int32_t* d_token,
+static __global__ __launch_bounds__(KH_WG) void k_set_state(int token, int pos, int32_t* d_token,
                                                      int32_t* d_pos, const float* tok_emb,
                                                      float* x, int dim) {
   if (threadIdx.x == 0) {

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(KH_WG) void k_pg_rmsnorm(const float* __restrict__ 
 
 // RoPE of the T query rows and of the T fresh key rows, in place (cpu/rope_kernel.cpp:18-42 half,
 // :98-121 interleaved); token t sits at position pos0 + t.  blockIdx.x = token.
-__global__ __launch_bounds__(KH_WG) void k_pg_rope(float* __restrict__ Q, float* __restrict__ kc,
+static __global__ __launch_bounds__(KH_WG) void k_pg_rope(float* __restrict__ Q, float* __restrict__ kc,
                                                    const float* __restrict__ sin_cache,
                                                    const float* __restrict__ cos_cache, int dim,
                                                    int kv_dim, int hs, int pos0, int mode) {

@@ -229,13 +229,11 @@ struct Gemv<true, U> {
 // one wave per pair leaves 4 waves per CU and no load/compute overlap.  comb = LDS float[8].
 // G: the matrix view - Gemv<QUANT, U>, or any class with its interface (kU, Regs, Rows, Mc, load,
 // load1, fma, fma1; tools/mb_gemv_ladder.hip plugs in stream-only views to price each ingredient).
-// DEPTH (1 or 2): register tiles a wave keeps in flight.  2 = the tiles of the wave's first TWO work
-// items are requested in the prologue (twice the bytes in flight while the input vector is staged,
-// and for matrices with <= 2 items per wave - wo, w2 - everything is in flight from the start);
-// needs one chunk per column range (host-checked).  ROLL: slot-by-slot refill (see below) or
-// "consume the tile, then request the next".
-template <int SPLIT, int DEPTH = 1, bool ROLL = true, class G, class PairFn, class PreFn, class IssueFn,
-          class FinishFn, class EpiFn>
+// Measured and not kept (profiles/r3_gemv_ladder_depth_roll.txt, commit 0f6b0a3^): a second register
+// tile requested in the prologue as well (two work items in flight per wave) - no gain on any
+// Llama-2-7B int8 shape, +70 VGPRs; and "consume the tile, then request the next" instead of the
+// slot-by-slot refill - equal within noise.
+template <int SPLIT, class G, class PairFn, class PreFn, class IssueFn, class FinishFn, class EpiFn>
 __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int total, int lane,
                                            float* comb, PairFn&& PAIR, PreFn&& PRE, IssueFn&& ISSUE,
                                            FinishFn&& FINISH, EpiFn&& EPI) {
@@ -268,13 +266,6 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
   // The loads stay in flight across the staging barriers.
   g.load(regs, cur, cb, ce, lane);
   auto aux = PRE(p0);
-  typename G::Regs regs_b;  // second ring slot (DEPTH == 2)
-  auto aux_b = aux;
-  if constexpr (DEPTH == 2) {
-    const int p1 = gp + np < total ? gp + np : p0;
-    g.load(regs_b, PAIR(p1), cb, ce, lane);
-    aux_b = PRE(p1);
-  }
   FINISH();
   const int iters = (total + np - 1) / np;  // uniform trip count: the SPLIT path has barriers
   // The tile registers ROLL: slot u of the next tile is requested right after slot u of the current
@@ -308,38 +299,6 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
       __syncthreads();
     }
   };
-  if constexpr (DEPTH == 2) {
-    // work item p lives in ring slot r; consuming it re-requests the slot for item p + 2*np
-    auto item = [&](typename G::Regs& r, decltype(aux)& ax, int p) __attribute__((always_inline)) {
-      const bool valid = p < total;
-      const int pn = p + 2 * np;
-      float a0 = 0.f, a1 = 0.f;
-      auto ax_next = ax;
-      if (pn < total) {
-        const typename G::Rows nxt = PAIR(pn);
-        if constexpr (ROLL) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            g.fma1(r, xs, cb, ce, lane, u, a0, a1);
-            g.load1(r, nxt, cb, ce, lane, u);
-          }
-        } else {
-          g.fma(r, xs, cb, ce, lane, a0, a1);
-          g.load(r, nxt, cb, ce, lane);
-        }
-        ax_next = PRE(pn);
-      } else if (valid) {
-        g.fma(r, xs, cb, ce, lane, a0, a1);
-      }
-      finish_item(p, valid, a0, a1, ax);
-      ax = ax_next;
-    };
-    for (int it = 0; it < iters; it += 2) {
-      item(regs, aux, gp + it * np);
-      if (it + 1 < iters) item(regs_b, aux_b, gp + (it + 1) * np);
-    }
-    return;
-  }
   // ONE loop over the wave's tiles (pair, chunk) in order, a single body that consumes slot u and
   // re-requests it for the following tile - the next chunk of the same rows or the first chunk of
   // the wave's next pair.  (A second loop body for multi-chunk rows next to a rolling one doubled
@@ -357,15 +316,10 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
     if (more) {
       typename G::Rows nxt = cur;
       if (last) nxt = PAIR(pn);
-      if constexpr (ROLL) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          g.fma1(regs, xs, c0, ce, lane, u, a0, a1);
-          g.load1(regs, nxt, cn, ce, lane, u);
-        }
-      } else {
-        g.fma(regs, xs, c0, ce, lane, a0, a1);
-        g.load(regs, nxt, cn, ce, lane);
+      for (int u = 0; u < U; ++u) {
+        g.fma1(regs, xs, c0, ce, lane, u, a0, a1);
+        g.load1(regs, nxt, cn, ce, lane, u);
       }
       cur = nxt;
     } else if (valid) {

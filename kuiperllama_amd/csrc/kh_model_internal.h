@@ -1,0 +1,116 @@
+// kh_model_internal.h — state and cross-unit helpers of the model level of the C-ABI.
+// The model level is split into four translation units:
+//   kh_model_load.hip     .bin image -> HBM arena, weight table, buffers, create / destroy, cache I/O
+//   kh_model_step.hip     launch shapes, the fused and unfused decode step, hipGraph capture,
+//                         predict / generate (kh_fused.h kernels are instantiated here)
+//   kh_model_prefill.hip  B-token VALU prefill and the MFMA GEMM prefill (kh_prefill.h, kh_gemm.h,
+//                         kh_pattn.h kernels)
+//   kh_model_profile.hip  per-kernel / per-step timing entry points
+// gfx950 only.  No CPU fallback: every path launches HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "kh_attn.h"
+#include "kh_common.h"
+
+namespace khm {
+struct LayerW {
+  KhLin wq, wk, wv, wo, w1, w2, w3;
+  const float* att_norm;
+  const float* ffn_norm;
+};
+
+}  // namespace khm
+using khm::LayerW;
+
+struct kh_model {
+  kh_config cfg{};
+  kh_model_opts opts{};
+  hipStream_t stream = nullptr;
+  // weights: one arena holding the .bin bytes after the header, in file order
+  char* arena = nullptr;
+  bool owns_arena = false;
+  size_t arena_bytes = 0;
+  std::vector<LayerW> layers;
+  const float* tok_emb = nullptr;
+  const float* final_norm = nullptr;
+  KhLin cls{};
+  int gshift = 0;
+  // activations / caches (llama3.cpp:425-500)
+  float *x = nullptr, *rms = nullptr, *q = nullptr, *att = nullptr, *h1 = nullptr,
+        *h3 = nullptr, *w2o = nullptr, *logits = nullptr, *score = nullptr, *kcache = nullptr,
+        *vcache = nullptr, *sin_cache = nullptr, *cos_cache = nullptr;
+  float* part_val = nullptr;
+  int32_t* part_idx = nullptr;
+  int nparts = 0;
+  float load_ms = 0.f;      // host image -> HBM upload time (kh_model_get_load_ms)
+  void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
+  int attn_ns = 1;
+  int attn_ns_g = 0;        // GQA long-context path: splits per KV group (0 = path off)
+  int attn_ws_stride = 1;   // split slots per head in attn_ws
+  int attn_t_long = 1 << 30;
+  int attn_wg = KH_WG;
+  int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
+          *d_words = nullptr;
+  int seq_cap = 0;  // capacity of d_forced / d_words
+  // prefill (kh_prefill.h): residual / q / attention / hidden rows of up to KH_PF_BMAX prompt tokens
+  float *pf_x = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
+  void* pf_ws = nullptr;        // KH_PF_BMAX attention split workspaces
+  size_t pf_ws_tok_bytes = 0;
+  // GEMM prefill (kh_gemm.h): slabs of KH_PG_TMAX token rows
+  float *pg_x = nullptr, *pg_xn = nullptr, *pg_q = nullptr, *pg_att = nullptr, *pg_h = nullptr;
+  void* pg_ws = nullptr;        // KH_PG_TMAX attention split workspaces
+  size_t pg_ws_tok_bytes = 0;
+  bool pf_ready = false, pg_ready = false;  // set when ALL prefill slabs exist (allocation can fail half-way)
+  bool pg_launch_failed = false;
+  int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check)
+  int pin_cap = 0;
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};
+  // launch geometry
+  struct Shape {
+    int u = 2, split = 1, grid = 1, wg = KH_WG;
+  };
+  Shape sh_qkv, sh_wo, sh_ffn, sh_w2, sh_cls;
+  // graph
+  // the decode step captured once as a 1-step graph and once as a KH_GRAPH_STEPS-step graph:
+  // consecutive hipGraphLaunch calls leave the GPU idle for ~8 us (measured), so the long
+  // graph amortises that gap over several tokens
+  hipGraph_t graph = nullptr, graphN = nullptr;
+  hipGraphExec_t gexec = nullptr, gexecN = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define KH_GRAPH_STEPS 8
+#define KH_PG_MIN_TOKENS 16  // prompts with fewer fed-only tokens stay on the bit-identical path
+
+namespace khm {
+template <typename T>
+int dalloc(T** p, size_t n) {
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  return e == hipSuccess ? KH_OK : (int)e;
+}
+
+// ---- kh_model_step.hip ----------------------------------------------------------------------
+kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const char* env, int wg = KH_WG,
+                           int wg_max = KH_WG, bool many_waves = false);
+int configure_step_kernels(kh_model* m);  // >64 KiB dynamic-LDS opt-in of the hidden-sized GEMVs
+KhAttnArgs fill_attn(kh_model* m, int l);
+void launch_qkv(kh_model* m, int l);
+void launch_attn(kh_model* m, int l);
+void launch_wo(kh_model* m, int l);
+void launch_ffn13(kh_model* m, int l);
+void launch_w2(kh_model* m, int l);
+void launch_cls(kh_model* m);
+void launch_sample(kh_model* m, int advance, int n_forced);
+void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev);
+int launch_step_unfused(kh_model* m, int pos);
+void set_state(kh_model* m, int token, int pos);
+int ensure_pinned_words(kh_model* m, int n);
+int ensure_seq_cap(kh_model* m, int n);
+int ensure_graph(kh_model* m, int n_forced);
+// ---- kh_model_prefill.hip -------------------------------------------------------------------
+bool prefill_supported(const kh_model* m);  // B-token VALU path
+bool pg_supported(const kh_model* m);       // MFMA GEMM path
+}  // namespace khm

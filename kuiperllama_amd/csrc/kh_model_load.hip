@@ -1,0 +1,513 @@
+// kh_model_load.hip — model level of the C-ABI, loader side: .bin image -> HBM arena, weight table,
+// activation / cache buffers, create / destroy, cache and logits I/O.  Replaces
+//   model::Model::read_model_file / generate_model_infos   kuiper/source/model/model.cpp:41-151
+//   LLama2Model::create_param_layers / _quant_layers       kuiper/source/model/llama3.cpp:184-423
+//   Qwen2Model::create_param_layers (q/k/v bias)           kuiper/source/model/qwen2.cpp:290-426
+//   LLama2Model::init_mem                                  llama3.cpp:425-500
+// gfx950 only.
+#include <fcntl.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "kh_model_internal.h"
+
+using namespace khm;
+
+namespace {
+
+int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+// Host image (typically the mmap of a .bin file: pageable, possibly not yet paged in) -> HBM.
+// A plain hipMemcpy from pageable memory is staged by the driver in small pieces; here two
+// pinned 64 MiB buffers are filled by a helper thread (page-in + memcpy) while the previous
+// buffer is in flight on the copy engine, so disk/page-cache reads, the host memcpy and the
+// PCIe transfer overlap.  Matters for the 27 GB fp32 7B image of the 8-replica config.
+hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t stream,
+                          float* ms_out) {
+  const size_t CH = (size_t)64 << 20;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n <= CH) {
+    hipError_t e = hipMemcpy(d_dst, h_src, n, hipMemcpyHostToDevice);
+    if (ms_out)
+      *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return e;
+  }
+  char* pin[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipHostMalloc((void**)&pin[i], CH, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) {
+    const size_t nchunks = (n + CH - 1) / CH;
+    auto fill = [&](size_t c) {  // helper-thread body: page-in + copy chunk c into its pinned buffer
+      const size_t off = c * CH, len = off + CH <= n ? CH : n - off;
+      memcpy(pin[c & 1], h_src + off, len);
+    };
+    std::thread filler(fill, (size_t)0);
+    for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
+      filler.join();  // chunk c is staged
+      const size_t off = c * CH, len = off + CH <= n ? CH : n - off;
+      e = hipMemcpyAsync(d_dst + off, pin[c & 1], len, hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) e = hipEventRecord(done[c & 1], stream);
+      if (c + 1 < nchunks) {
+        // the other buffer was last used by chunk c-1: wait for that transfer, then refill it
+        if (c >= 1 && e == hipSuccess) e = hipEventSynchronize(done[(c + 1) & 1]);
+        filler = std::thread(fill, c + 1);
+      }
+    }
+    if (filler.joinable()) filler.join();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (done[i]) (void)hipEventDestroy(done[i]);
+    if (pin[i]) (void)hipHostFree(pin[i]);
+  }
+  if (ms_out)
+    *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return e;
+}
+
+// ---- weight table ------------------------------------------------------------------------
+// Byte offsets are relative to the weight data (= file bytes after the header), mirroring
+// kuiperllama_amd/binfmt.py::layout.
+int build_weight_table(kh_model* m) {
+  const kh_config& c = m->cfg;
+  const int L = c.layer_num, dim = c.dim, kvd = c.kv_dim, hid = c.hidden_dim, V = c.vocab_size;
+  m->layers.assign((size_t)L, LayerW{});
+  char* base = m->arena;
+  size_t off = 0;
+  if (!c.is_quant) {
+    const bool bias = c.family == KH_FAMILY_QWEN2;
+    auto takef = [&](size_t n) {
+      const float* p = (const float*)(base + off);
+      off += n * sizeof(float);
+      return p;
+    };
+    m->tok_emb = takef((size_t)V * dim);
+    for (int l = 0; l < L; ++l) m->layers[l].att_norm = takef((size_t)dim);
+    for (int l = 0; l < L; ++l) {
+      m->layers[l].wq.w = takef((size_t)dim * dim);
+      if (bias) m->layers[l].wq.bias = takef((size_t)dim);
+    }
+    for (int l = 0; l < L; ++l) {
+      m->layers[l].wk.w = takef((size_t)kvd * dim);
+      if (bias) m->layers[l].wk.bias = takef((size_t)kvd);
+    }
+    for (int l = 0; l < L; ++l) {
+      m->layers[l].wv.w = takef((size_t)kvd * dim);
+      if (bias) m->layers[l].wv.bias = takef((size_t)kvd);
+    }
+    for (int l = 0; l < L; ++l) m->layers[l].wo.w = takef((size_t)dim * dim);
+    for (int l = 0; l < L; ++l) m->layers[l].ffn_norm = takef((size_t)dim);
+    for (int l = 0; l < L; ++l) m->layers[l].w1.w = takef((size_t)hid * dim);
+    for (int l = 0; l < L; ++l) m->layers[l].w2.w = takef((size_t)dim * hid);
+    for (int l = 0; l < L; ++l) m->layers[l].w3.w = takef((size_t)hid * dim);
+    m->final_norm = takef((size_t)dim);
+    (void)takef((size_t)c.seq_len * c.head_size);  // freqs_cos + freqs_sin: skipped (:367-368)
+    if (c.is_shared_weight) {
+      m->cls.w = m->tok_emb;  // llama3.cpp:372-375
+    } else {
+      m->cls.w = takef((size_t)V * dim);
+    }
+  } else {
+    const size_t gs = (size_t)c.group_size;
+    auto takeq = [&](KhLin& Lw, size_t K, size_t M) {
+      const size_t n = K * M;
+      Lw.w = base + off;
+      Lw.scales = (const float*)(base + off + n);  // layer.cpp:209-215
+      off += n + (n / gs) * sizeof(float);
+    };
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wq, dim, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wk, kvd, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wv, kvd, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].wo, dim, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].w1, hid, dim);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].w2, dim, hid);
+    for (int l = 0; l < L; ++l) takeq(m->layers[l].w3, hid, dim);
+    takeq(m->cls, V, dim);
+    const float* fp = (const float*)(base + off);
+    m->tok_emb = fp;
+    fp += (size_t)V * dim;
+    for (int l = 0; l < L; ++l) m->layers[l].att_norm = fp + (size_t)l * dim;
+    fp += (size_t)L * dim;
+    for (int l = 0; l < L; ++l) m->layers[l].ffn_norm = fp + (size_t)l * dim;
+    fp += (size_t)L * dim;
+    m->final_norm = fp;
+    fp += dim;
+    off = (size_t)((const char*)fp - base);
+  }
+  if (off > m->arena_bytes) return KH_ERR_FORMAT;
+  return KH_OK;
+}
+
+int parse_header(const int32_t* h, const kh_model_opts* o, kh_config* c) {
+  // model.cpp:57-71, 125-151
+  memset(c, 0, sizeof(*c));
+  c->dim = h[0];
+  c->hidden_dim = h[1];
+  c->layer_num = h[2];
+  c->head_num = h[3];
+  c->kv_head_num = h[4];
+  c->is_shared_weight = h[5] > 0;
+  c->vocab_size = h[5] < 0 ? -h[5] : h[5];
+  c->seq_len = h[6];
+  c->is_quant = o->is_quant ? 1 : 0;
+  c->group_size = o->is_quant ? h[7] : 0;
+  if (c->dim <= 0 || c->hidden_dim <= 0 || c->layer_num <= 0 || c->head_num <= 0 ||
+      c->kv_head_num <= 0 || c->vocab_size <= 0 || c->seq_len <= 0)
+    return KH_ERR_FORMAT;
+  if (c->dim % c->head_num || c->head_num % c->kv_head_num) return KH_ERR_FORMAT;
+  c->kv_dim = (c->dim * c->kv_head_num) / c->head_num;
+  c->kv_mul = c->head_num / c->kv_head_num;
+  c->head_size = c->dim / c->head_num;
+  c->family = o->family;
+  c->rope_mode = o->rope_mode;
+  c->rope_theta = o->rope_theta;
+  c->rms_eps = o->rms_eps;
+  c->cache_len = (o->max_seq_len > 0 && o->max_seq_len < c->seq_len) ? o->max_seq_len : c->seq_len;
+  if (c->is_quant) {
+    if (c->group_size <= 0) return KH_ERR_FORMAT;
+    // the reference wires an int8 classifier onto fp32 embedding bytes when the classifier
+    // is tied (llama3.cpp:259-262) and has no Qwen2 int8 bias layout: refuse both
+    if (c->is_shared_weight || c->family == KH_FAMILY_QWEN2) return KH_ERR_UNSUPPORTED;
+  }
+  if (o->rope_mode != KH_ROPE_HALF && o->rope_mode != KH_ROPE_INTERLEAVED) return KH_ERR_INVALID_ARG;
+  if (o->family != KH_FAMILY_LLAMA && o->family != KH_FAMILY_QWEN2) return KH_ERR_INVALID_ARG;
+  if (!(o->rope_theta > 0.f) || !(o->rms_eps > 0.f)) return KH_ERR_INVALID_ARG;
+  // vector-path preconditions of the fused kernels
+  const int a = c->is_quant ? 16 : 4;
+  if (c->dim % a || c->hidden_dim % a || c->head_size % 4 || (c->head_size & 1) ||
+      c->head_size > 256 || c->kv_dim % 4 || (c->dim & 1) || (c->kv_dim & 1))
+    return KH_ERR_UNSUPPORTED;
+  if (c->is_quant) {
+    const int gs = ilog2_exact(c->group_size);
+    if (gs < 4 || c->dim % c->group_size || c->hidden_dim % c->group_size) return KH_ERR_UNSUPPORTED;
+  }
+  return KH_OK;
+}
+
+size_t expected_weight_bytes(const kh_config& c) {
+  const size_t L = c.layer_num, dim = c.dim, kvd = c.kv_dim, hid = c.hidden_dim, V = c.vocab_size;
+  const size_t lin = L * (2 * dim * dim + 2 * kvd * dim + 3 * hid * dim);
+  if (!c.is_quant) {
+    size_t n = V * dim + 2 * L * dim + lin + dim + (size_t)c.seq_len * c.head_size;
+    if (c.family == KH_FAMILY_QWEN2) n += L * (dim + 2 * kvd);
+    if (!c.is_shared_weight) n += V * dim;
+    return n * sizeof(float);
+  }
+  const size_t q = lin + V * dim;
+  return q + (q / (size_t)c.group_size) * sizeof(float) + (V * dim + 2 * L * dim + dim) * sizeof(float);
+}
+
+int finish_create(kh_model* m) {
+  const kh_config& c = m->cfg;
+  int rc;
+  if ((rc = build_weight_table(m)) != KH_OK) return rc;
+  m->gshift = c.is_quant ? ilog2_exact(c.group_size) : 0;
+  const size_t CL = (size_t)c.cache_len;
+#define KH_ALLOC(ptr, n) \
+  if ((rc = dalloc(&(ptr), (n))) != KH_OK) return rc
+  KH_ALLOC(m->x, (size_t)c.dim);
+  KH_ALLOC(m->rms, (size_t)c.dim);
+  KH_ALLOC(m->q, (size_t)c.dim);
+  KH_ALLOC(m->att, (size_t)c.dim);
+  KH_ALLOC(m->w2o, (size_t)c.dim);
+  KH_ALLOC(m->h1, (size_t)c.hidden_dim);
+  KH_ALLOC(m->h3, (size_t)c.hidden_dim);
+  KH_ALLOC(m->logits, (size_t)c.vocab_size);
+  KH_ALLOC(m->score, (size_t)c.head_num * CL);
+  KH_ALLOC(m->kcache, (size_t)c.layer_num * CL * c.kv_dim);
+  KH_ALLOC(m->vcache, (size_t)c.layer_num * CL * c.kv_dim);
+  KH_ALLOC(m->sin_cache, CL * c.head_size);
+  KH_ALLOC(m->cos_cache, CL * c.head_size);
+  KH_ALLOC(m->d_pos, 1);
+  KH_ALLOC(m->d_token, 1);
+  KH_ALLOC(m->d_next, 1);
+  // launch geometry
+  m->sh_qkv = pick_shape(c.is_quant, (c.dim + 2 * c.kv_dim) / 2, c.dim, 2, "KH_SHAPE_QKV", KH_WG,
+                         KH_WG_MAX);
+  m->sh_wo = pick_shape(c.is_quant, c.dim / 2, c.dim, 4, "KH_SHAPE_WO", KH_WG, KH_WG_MAX, true);
+  m->sh_ffn = pick_shape(c.is_quant, c.hidden_dim, c.dim, 1, "KH_SHAPE_FFN", KH_WG, KH_WG_MAX);
+  // w2 re-stages the hidden-sized input in every workgroup: 512-thread workgroups halve that
+  // L2 -> LDS traffic for the same number of waves (measured 14.1 -> 11.8 us on Llama-3.2-1B)
+  m->sh_w2 = pick_shape(c.is_quant, c.dim / 2, c.hidden_dim, 4, "KH_SHAPE_W2", KH_WG_MAX, KH_WG_MAX,
+                        true);
+  m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS",
+                         c.is_quant ? KH_WG : KH_WG_MAX, KH_WG_MAX);
+  m->nparts = m->sh_cls.grid;
+  if (getenv("KH_SHAPE_DEBUG")) {
+    const struct { const char* n; const kh_model::Shape* s; } all[] = {
+        {"qkv", &m->sh_qkv}, {"wo", &m->sh_wo}, {"ffn13", &m->sh_ffn}, {"w2", &m->sh_w2}, {"cls", &m->sh_cls}};
+    for (const auto& e : all)
+      fprintf(stderr, "[kh] shape %-5s split %d u %d grid %d wg %d\n", e.n, e.s->split, e.s->u, e.s->grid, e.s->wg);
+  }
+  m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
+  // attention: 8 waves per (head, split) shorten each lane's timestep loop
+  m->attn_wg = KH_WG_MAX;
+  if (const char* e = getenv("KH_ATTN_WG"))
+    if (atoi(e) == 256 || atoi(e) == 512) m->attn_wg = atoi(e);
+  // GQA long-context path (kh_attn.h): one workgroup per (kv group, split) from pos + 1 >=
+  // t_long on; KH_ATTN_TLONG overrides the threshold (0 = never)
+  m->attn_ws_stride = m->attn_ns;
+  if (c.kv_mul > 1 && c.head_size > 32 &&
+      attn_group_supported(c.head_size, c.kv_mul, m->attn_wg)) {
+    // default policy: models with few KV heads (Qwen2.5-0.5B: 2) cannot fill the chip with
+    // (group, split) workgroups and stay per-head; an explicit KH_ATTN_TLONG overrides
+    int t_long = c.kv_head_num >= KH_ATTN_MIN_GROUPS ? KH_ATTN_TLONG_DEFAULT : 0;
+    if (const char* e = getenv("KH_ATTN_TLONG")) t_long = atoi(e);
+    if (t_long > 0 && t_long <= (int)c.cache_len) {
+      m->attn_ns_g = attn_group_splits(c.cache_len, c.kv_head_num);
+      m->attn_t_long = t_long;
+      if (m->attn_ns_g > m->attn_ws_stride) m->attn_ws_stride = m->attn_ns_g;
+    }
+  }
+  if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride)) {
+    KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
+    KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));
+  }
+  KH_ALLOC(m->part_val, (size_t)m->nparts);
+  KH_ALLOC(m->part_idx, (size_t)m->nparts);
+#undef KH_ALLOC
+  KH_CHECK_HIP(hipMemsetAsync(m->kcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
+  KH_CHECK_HIP(hipMemsetAsync(m->vcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
+  KH_CHECK_HIP(hipMemsetAsync(m->d_pos, 0, sizeof(int32_t), m->stream));
+  KH_CHECK_HIP(hipMemsetAsync(m->d_token, 0, sizeof(int32_t), m->stream));
+  // sin/cos table: computed on the host with libm exactly as the CPU backend does
+  // (cpu/rope_kernel.cpp:4-16) so the fp32 table is bit-identical to the CPU reference's,
+  // then uploaded once.  (kh_sincos_cache_f32 is the on-device twin of sin_cos_cache_calc_cu.)
+  {
+    const size_t n = CL * c.head_size;
+    std::vector<float> hs_(n), hc_(n);
+    std::vector<float> freq((size_t)c.head_size);
+    for (int d = 0; d < c.head_size; ++d)
+      freq[d] = 1.0f / powf(c.rope_theta, (float)d / (float)c.head_size);
+    for (size_t p = 0; p < CL; ++p)
+      for (int d = 0; d < c.head_size; ++d) {
+        const float val = (float)p * freq[d];
+        hs_[p * c.head_size + d] = sinf(val);
+        hc_[p * c.head_size + d] = cosf(val);
+      }
+    KH_CHECK_HIP(hipMemcpy(m->sin_cache, hs_.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    KH_CHECK_HIP(hipMemcpy(m->cos_cache, hc_.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if ((rc = configure_step_kernels(m)) != KH_OK) return rc;
+  KH_CHECK_HIP(hipEventCreate(&m->ev0));
+  KH_CHECK_HIP(hipEventCreate(&m->ev1));
+  if ((rc = ensure_seq_cap(m, 256)) != KH_OK) return rc;
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+
+int new_model(const int32_t* h_header, const kh_model_opts* opts, kh_model** out) {
+  if (!h_header || !opts || !out) return KH_ERR_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return KH_ERR_NO_DEVICE;
+  }
+  if (opts->device < 0 || opts->device >= ndev) return KH_ERR_INVALID_ARG;
+  kh_config cfg;
+  int rc = parse_header(h_header, opts, &cfg);
+  if (rc != KH_OK) return rc;
+  KH_CHECK_HIP(hipSetDevice(opts->device));
+  kh_model* m = new (std::nothrow) kh_model();
+  if (!m) return (int)hipErrorOutOfMemory;
+  m->cfg = cfg;
+  m->opts = *opts;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete m;
+    return (int)e;
+  }
+  *out = m;
+  return KH_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" void kh_model_destroy(kh_model* m) {
+  if (!m) return;
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+  if (m->gexecN) (void)hipGraphExecDestroy(m->gexecN);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  if (m->graphN) (void)hipGraphDestroy(m->graphN);
+  if (m->ev0) (void)hipEventDestroy(m->ev0);
+  if (m->ev1) (void)hipEventDestroy(m->ev1);
+  for (void* q : {(void*)m->pf_x, (void*)m->pf_q, (void*)m->pf_att, (void*)m->pf_h, m->pf_ws,
+                  (void*)m->pg_x, (void*)m->pg_xn, (void*)m->pg_q, (void*)m->pg_att, (void*)m->pg_h,
+                  m->pg_ws})
+    if (q) (void)hipFree(q);
+  for (auto e : m->ev_chunk)
+    if (e) (void)hipEventDestroy(e);
+  if (m->h_words_pin) (void)hipHostFree(m->h_words_pin);
+  void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
+                  m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
+                  m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
+                  m->d_forced, m->d_words, m->attn_ws};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (m->owns_arena && m->arena) (void)hipFree(m->arena);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" int kh_model_create_from_device_weights(const int32_t* h_header,
+                                                   const void* d_weight_data,
+                                                   size_t weight_nbytes,
+                                                   const kh_model_opts* opts, kh_model** out) {
+  if (!d_weight_data || !kh_aligned16(d_weight_data)) return KH_ERR_INVALID_ARG;
+  if (!out) return KH_ERR_INVALID_ARG;
+  *out = nullptr;
+  kh_model* m = nullptr;
+  int rc = new_model(h_header, opts, &m);
+  if (rc != KH_OK) return rc;
+  if (weight_nbytes < expected_weight_bytes(m->cfg)) {
+    kh_model_destroy(m);
+    *out = nullptr;
+    return KH_ERR_FORMAT;
+  }
+  m->arena = (char*)const_cast<void*>(d_weight_data);
+  m->owns_arena = false;
+  m->arena_bytes = weight_nbytes;
+  m->cfg.weight_bytes = (int64_t)expected_weight_bytes(m->cfg);
+  rc = finish_create(m);
+  if (rc != KH_OK) {
+    kh_model_destroy(m);
+    m = nullptr;
+  }
+  *out = m;
+  return rc;
+}
+
+extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbytes,
+                                               const kh_model_opts* opts, kh_model** out) {
+  if (!h_image || !opts || !out) return KH_ERR_INVALID_ARG;
+  const size_t hdr = opts->is_quant ? 32 : 28;
+  if (nbytes < hdr) return KH_ERR_FORMAT;
+  int32_t header[8] = {0};
+  memcpy(header, h_image, hdr);
+  *out = nullptr;
+  kh_model* m = nullptr;
+  int rc = new_model(header, opts, &m);
+  if (rc != KH_OK) return rc;
+  const size_t need = expected_weight_bytes(m->cfg);
+  if (nbytes - hdr < need) {
+    kh_model_destroy(m);
+    *out = nullptr;
+    return KH_ERR_FORMAT;
+  }
+  hipError_t e = hipMalloc((void**)&m->arena, need);
+  if (e == hipSuccess) {
+    m->owns_arena = true;
+    m->arena_bytes = need;
+    // weights go up once, in file order, into one arena (the reference cudaMallocs and copies
+    // every tensor separately: tensor.cpp:104-119)
+    e = upload_chunked(m->arena, (const char*)h_image + hdr, need, m->stream, &m->load_ms);
+  }
+  if (e != hipSuccess) {
+    kh_model_destroy(m);
+    *out = nullptr;
+    return (int)e;
+  }
+  m->cfg.weight_bytes = (int64_t)need;
+  rc = finish_create(m);
+  if (rc != KH_OK) {
+    kh_model_destroy(m);
+    m = nullptr;
+  }
+  *out = m;
+  return rc;
+}
+
+extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* opts,
+                                         kh_model** out) {
+  if (!path || !opts || !out) return KH_ERR_INVALID_ARG;
+  // model.cpp:41-123: open + fstat + mmap(PROT_READ, MAP_PRIVATE)
+  const int fd = open(path, O_RDONLY);
+  if (fd == -1) return KH_ERR_IO;
+  struct stat st;
+  if (fstat(fd, &st) == -1 || st.st_size <= 0) {
+    close(fd);
+    return KH_ERR_IO;
+  }
+  void* data = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  if (data == MAP_FAILED || data == nullptr) {
+    close(fd);
+    return KH_ERR_IO;
+  }
+  const int rc = kh_model_create_from_host_image(data, (size_t)st.st_size, opts, out);
+  munmap(data, (size_t)st.st_size);
+  close(fd);
+  return rc;
+}
+
+extern "C" int kh_model_get_config(const kh_model* m, kh_config* out) {
+  if (!m || !out) return KH_ERR_INVALID_ARG;
+  *out = m->cfg;
+  out->launches_per_token = 5 * m->cfg.layer_num + 2;
+  return KH_OK;
+}
+extern "C" float kh_model_get_load_ms(const kh_model* m) { return m ? m->load_ms : -1.f; }
+extern "C" void* kh_model_stream(kh_model* m) { return m ? (void*)m->stream : nullptr; }
+
+extern "C" int kh_model_get_logits(kh_model* m, float* h_logits) {
+  if (!m || !h_logits) return KH_ERR_INVALID_ARG;
+  KH_CHECK_HIP(hipMemcpyAsync(h_logits, m->logits, sizeof(float) * m->cfg.vocab_size,
+                              hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+extern "C" int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache) {
+  if (!m || !d_kcache || !d_vcache) return KH_ERR_INVALID_ARG;
+  *d_kcache = m->kcache;
+  *d_vcache = m->vcache;
+  return KH_OK;
+}
+
+extern "C" int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows,
+                                float* h_k, float* h_v) {
+  if (!m || !h_k || !h_v || layer < 0 || layer >= m->cfg.layer_num || row0 < 0 || nrows <= 0 ||
+      (int64_t)row0 + nrows > m->cfg.cache_len)
+    return KH_ERR_INVALID_ARG;
+  const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
+  const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
+  KH_CHECK_HIP(hipMemcpyAsync(h_k, m->kcache + off, nb, hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipMemcpyAsync(h_v, m->vcache + off, nb, hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+
+extern "C" int kh_model_write_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows,
+                                 const float* h_k, const float* h_v) {
+  if (!m || !h_k || !h_v || layer < 0 || layer >= m->cfg.layer_num || row0 < 0 || nrows <= 0 ||
+      (int64_t)row0 + nrows > m->cfg.cache_len)
+    return KH_ERR_INVALID_ARG;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
+  const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
+  // hipMemcpyDefault: the source may be host memory or memory of this device (unified addressing)
+  KH_CHECK_HIP(hipMemcpyAsync(m->kcache + off, h_k, nb, hipMemcpyDefault, m->stream));
+  KH_CHECK_HIP(hipMemcpyAsync(m->vcache + off, h_v, nb, hipMemcpyDefault, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}

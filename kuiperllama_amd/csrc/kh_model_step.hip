@@ -1,0 +1,669 @@
+// kh_model_step.hip — the decode step of the model level: launch shapes, the fused (5L+2 launches)
+// and unfused (the reference's own sequence) step, hipGraph capture, predict and the generate loop.
+// Replaces, for the decode path,
+//   LLama2Model::forward / predict                         kuiper/source/model/llama3.cpp:147-167, 642-650
+//   generate()                                             demo/main.cpp:5-47
+// gfx950 only.  No CPU fallback: every path below launches HIP kernels.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kh_fused.h"
+#include "kh_model_internal.h"
+
+namespace khm {
+
+// Launch shape of one GEMV: rows are processed as `pairs` work items of two M-long rows.
+//  split: waves sharing a pair (1/2/4) — raised while the launch has < 4096 waves and each wave
+//         would still stream >= 8 KiB (fp32) / 4 KiB (int8);
+//  u    : 16-byte loads per row per lane in flight (covers the wave's column range when it can);
+//  grid : workgroups, <= 1024 (4 per CU), chosen so every wave gets the same number of items.
+kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const char* env, int wg,
+                           int wg_max, bool many_waves) {
+  kh_model::Shape sh;
+  sh.wg = wg;
+  // tuning hook (tools/sweep_shapes.py): KH_SHAPE_<K>="split,u,grid[,wg]" overrides the heuristic
+  if (const char* ov = env ? getenv(env) : nullptr) {
+    int sp = 0, u = 0, g = 0, w = wg;
+    const int nf = sscanf(ov, "%d,%d,%d,%d", &sp, &u, &g, &w);
+    if (nf >= 3 && (sp == 1 || sp == 2 || sp == 4) && sp <= max_split &&
+        (u == 2 || u == 4 || u == 8) && !(quant && u == 8) && g >= 1 && g <= 4096 &&
+        (w == 256 || (w == 512 && wg_max >= 512))) {
+      sh.split = sp;
+      sh.u = u;
+      sh.grid = g;
+      sh.wg = w;
+      return sh;
+    }
+  }
+  const int elem = quant ? 1 : 4;
+  const int min_bytes = quant ? 4096 : 8192;  // bytes one wave must still stream per pair
+  const long pair_bytes = 2L * M * elem;
+  // waves to aim for before rows are split.  With the rolling tile refill a wave that walks several
+  // chunks of a long row keeps its loads in flight, so fewer, longer-lived waves beat many short
+  // ones (r3 sweeps, profiles/r3_shape_sweep.md: Llama-2-7B w2 int8 split 4 -> 2: 12.6 -> 10.8 us,
+  // fp32 33.6 -> 31.4; wo int8 split 2 -> 1: 5.6 -> 5.25); rounds 1-2 aimed at twice as many.
+  const int target_waves = pair_bytes >= 16384 ? 4096 : 2048;
+  while (sh.split < max_split && pairs * sh.split < target_waves &&
+         pair_bytes / (sh.split * 2) >= min_bytes)
+    sh.split *= 2;
+  const int Mc = quant ? M / 16 : M / 4;
+  const int per_lane = ((Mc + sh.split - 1) / sh.split + KH_WAVE - 1) / KH_WAVE;
+  if (quant)
+    // one chunk when it covers the column range; ranges that need several chunks anyway take the
+    // small one (less padding in the last chunk, finer refill: w2 int8 u4 -> u2 11.9 -> 10.8 us)
+    sh.u = per_lane > 4 ? 2 : (per_lane >= 3 ? 4 : 2);
+  else
+    sh.u = per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
+  const int ppw = (wg / KH_WAVE) / sh.split;  // pairs per workgroup per iteration
+  const int need = (pairs + ppw - 1) / ppw;
+  // every workgroup re-stages the M-float input vector from L2: keep that below ~75 % of the
+  // weight bytes (matters for w2, whose input is the hidden-sized vector; sweep in
+  // profiles/r1_shape_sweep.md), and never more than 4 workgroups per CU
+  long cap = (long)(0.75 * (double)pairs * (double)pair_bytes / ((double)M * 4.0));
+  const long cap_hi = 1024L * KH_WG / wg, cap_lo = 256L * KH_WG / wg;  // 4 .. 1 x 256 threads / CU
+  if (cap > cap_hi) cap = cap_hi;
+  if (cap < cap_lo) cap = cap_lo;
+  if (need <= cap) {
+    sh.grid = need;
+  } else {
+    // several iterations per workgroup: keep the grid a whole number of workgroups per CU (256
+    // CUs; 384- or 688-wide grids measured 5-10 % slower than their balanced neighbours) and
+    // minimise the per-CU critical path (g/256)*ceil(need/g).  Ties: the many-row matrices
+    // (qkv, ffn13, cls) prefer 8 resident waves per CU, then 12, 16 -- fewer, longer-lived
+    // workgroups re-stage x less often; the few-long-row matrices (wo, w2: one or two chunks
+    // per wave) prefer 16 -- everything is in flight at once (profiles/r1_shape_sweep.md).
+    const int wpw = wg / KH_WAVE;           // waves per workgroup
+    // resident waves per CU, in order of preference
+    const int pref_lo[4] = {8, 12, 16, 4}, pref_hi[4] = {16, 12, 8, 4};
+    long best_cost = -1;
+    for (int wv : (many_waves ? pref_hi : pref_lo)) {
+      if (wv == 4 && best_cost >= 0) break;  // 4 waves per CU only when nothing else fits
+      if (wv % wpw) continue;
+      const long g = 256L * (wv / wpw);
+      if (g > cap) continue;
+      const long cost = g * ((need + g - 1) / g);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        sh.grid = (int)g;
+      }
+    }
+    if (best_cost < 0) sh.grid = (int)cap;
+  }
+  return sh;
+}
+
+// ---- fused launches -------------------------------------------------------------------------
+// Template dispatch.  U: 16-byte loads per row in flight per lane; MV: in-register staging depth
+// (kh_stage_maxv of the input length); SP: waves sharing one row pair.
+// The workgroup size comes from a variable `kh_launch_wg` in scope at the dispatch site.
+#define KH_L3(KERNEL, Q, UU, MV, GRID, LDS, STREAM, ARGS) \
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
+#define KH_L4(KERNEL, Q, UU, MV, SP, GRID, LDS, STREAM, ARGS) \
+  hipLaunchKernelGGL((KERNEL<Q, UU, MV, SP>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
+#define KH_SEL_MV3(KERNEL, Q, UU, MV, ...)                  \
+  do {                                                      \
+    if ((MV) == 4)                                          \
+      KH_L3(KERNEL, Q, UU, 4, __VA_ARGS__);                 \
+    else                                                    \
+      KH_L3(KERNEL, Q, UU, 0, __VA_ARGS__);                 \
+  } while (0)
+#define KH_SEL_SP4(KERNEL, Q, UU, MV, SP, ...)              \
+  do {                                                      \
+    if ((SP) == 4)                                          \
+      KH_L4(KERNEL, Q, UU, MV, 4, __VA_ARGS__);             \
+    else if ((SP) == 2)                                     \
+      KH_L4(KERNEL, Q, UU, MV, 2, __VA_ARGS__);             \
+    else                                                    \
+      KH_L4(KERNEL, Q, UU, MV, 1, __VA_ARGS__);             \
+  } while (0)
+#define KH_SEL_MV4(KERNEL, Q, UU, MV, SP, ...)              \
+  do {                                                      \
+    if ((MV) == 4)                                          \
+      KH_SEL_SP4(KERNEL, Q, UU, 4, SP, __VA_ARGS__);        \
+    else                                                    \
+      KH_SEL_SP4(KERNEL, Q, UU, 0, SP, __VA_ARGS__);        \
+  } while (0)
+// k_gemv_res only: the 6-deep in-register staging for hidden-sized inputs (kh_stage_maxv)
+#define KH_SEL_MV4X(KERNEL, Q, UU, MV, SP, ...)             \
+  do {                                                      \
+    if ((MV) == 6)                                          \
+      KH_SEL_SP4(KERNEL, Q, UU, 6, SP, __VA_ARGS__);        \
+    else                                                    \
+      KH_SEL_MV4(KERNEL, Q, UU, MV, SP, __VA_ARGS__);       \
+  } while (0)
+#define KH_SEL_U(SEL, KERNEL, QUANT, U, ...)                \
+  do {                                                      \
+    if (QUANT) {                                            \
+      if ((U) >= 4)                                         \
+        SEL(KERNEL, true, 4, __VA_ARGS__);                  \
+      else                                                  \
+        SEL(KERNEL, true, 2, __VA_ARGS__);                  \
+    } else {                                                \
+      if ((U) >= 8)                                         \
+        SEL(KERNEL, false, 8, __VA_ARGS__);                 \
+      else if ((U) >= 4)                                    \
+        SEL(KERNEL, false, 4, __VA_ARGS__);                 \
+      else                                                  \
+        SEL(KERNEL, false, 2, __VA_ARGS__);                 \
+    }                                                       \
+  } while (0)
+// kernels without / with the SPLIT parameter
+#define KH_DISPATCH3(KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV3, KERNEL, QUANT, U, MV, GRID, LDS, STREAM, ARGS)
+#define KH_DISPATCH4(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV4, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
+#define KH_DISPATCH4X(KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS) \
+  KH_SEL_U(KH_SEL_MV4X, KERNEL, QUANT, U, MV, SP, GRID, LDS, STREAM, ARGS)
+
+KhQkvArgs fill_qkv(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const LayerW& W = m->layers[l];
+  KhQkvArgs a;
+  a.x = m->x;
+  a.att_norm = W.att_norm;
+  a.wq = W.wq;
+  a.wk = W.wk;
+  a.wv = W.wv;
+  a.q_out = m->q;
+  a.kcache_layer = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.vcache_layer = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.d_pos = m->d_pos;
+  a.sin_cache = m->sin_cache;
+  a.cos_cache = m->cos_cache;
+  a.dim = c.dim;
+  a.kv_dim = c.kv_dim;
+  a.head_size = c.head_size;
+  a.rope_mode = c.rope_mode;
+  a.gshift = m->gshift;
+  a.eps = c.rms_eps;
+  return a;
+}
+void launch_qkv(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const KhQkvArgs a = fill_qkv(m, l);
+  const bool qn = c.is_quant;
+  const int kh_launch_wg = m->sh_qkv.wg;
+  KH_DISPATCH4(k_qkv, qn, m->sh_qkv.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_qkv.split, m->sh_qkv.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
+}
+KhAttnArgs fill_attn(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  KhAttnArgs a;
+  a.q = m->q;
+  a.kcache_layer = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.vcache_layer = m->vcache + (size_t)l * c.cache_len * c.kv_dim;
+  a.out = m->att;
+  a.d_pos = m->d_pos;
+  a.kv_dim = c.kv_dim;
+  a.kv_mul = c.kv_mul;
+  a.head_size = c.head_size;
+  a.kv_heads = c.kv_head_num;
+  a.nsplit = m->attn_ns;
+  a.ws = m->attn_ws;
+  a.ws_stride = m->attn_ws_stride;
+  a.nsplit_g = m->attn_ns_g;
+  a.t_long = m->attn_t_long;
+  a.tok_stride = 0;
+  a.ws_tok_bytes = 0;
+  return a;
+}
+int attn_group_lanes(const kh_config& c) {
+  int G = 1;
+  while (G < c.head_size / 4) G <<= 1;
+  return G < 16 ? 16 : G;
+}
+void launch_attn(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const KhAttnArgs a = fill_attn(m, l);
+  const int wg = m->attn_wg;
+  if (c.head_size > 32)
+    launch_attn_decode(a, 0, wg, m->stream);
+  else  // head_size <= 32: generic LDS-score kernel (tiny test models)
+    hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(wg),
+                       attn_lds_bytes(c.head_size, wg), m->stream, a);
+}
+KhGemvResArgs fill_wo(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  KhGemvResArgs a;
+  a.vec = m->att;
+  a.w = m->layers[l].wo;
+  a.x = m->x;
+  a.M = c.dim;
+  a.K = c.dim;
+  a.gshift = m->gshift;
+  return a;
+}
+void launch_wo(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const KhGemvResArgs a = fill_wo(m, l);
+  const bool qn = c.is_quant;
+  const int kh_launch_wg = m->sh_wo.wg;
+  KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_wo.split, m->sh_wo.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
+}
+void launch_ffn13(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  const LayerW& W = m->layers[l];
+  KhFfn13Args a;
+  a.x = m->x;
+  a.ffn_norm = W.ffn_norm;
+  a.w1 = W.w1;
+  a.w3 = W.w3;
+  a.h = m->h1;
+  a.dim = c.dim;
+  a.hidden = c.hidden_dim;
+  a.gshift = m->gshift;
+  a.eps = c.rms_eps;
+  const bool qn = c.is_quant;
+  const int kh_launch_wg = m->sh_ffn.wg;
+  KH_DISPATCH3(k_ffn13, qn, m->sh_ffn.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_ffn.grid,
+               fused_lds_bytes(qn, c.dim), m->stream, a);
+}
+void launch_w2(kh_model* m, int l) {
+  const kh_config& c = m->cfg;
+  KhGemvResArgs a;
+  a.vec = m->h1;
+  a.w = m->layers[l].w2;
+  a.x = m->x;
+  a.M = c.hidden_dim;
+  a.K = c.dim;
+  a.gshift = m->gshift;
+  const bool qn = c.is_quant;
+  const int kh_launch_wg = m->sh_w2.wg;
+  KH_DISPATCH4X(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split, m->sh_w2.grid,
+                fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
+}
+void launch_cls(kh_model* m) {
+  const kh_config& c = m->cfg;
+  KhClsArgs a;
+  a.x = m->x;
+  a.final_norm = m->final_norm;
+  a.wcls = m->cls;
+  a.logits = m->logits;
+  a.part_val = m->part_val;
+  a.part_idx = m->part_idx;
+  a.dim = c.dim;
+  a.vocab = c.vocab_size;
+  a.gshift = m->gshift;
+  a.eps = c.rms_eps;
+  // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
+  const bool qn = c.is_quant;
+  const int kh_launch_wg = m->sh_cls.wg;
+  KH_DISPATCH3(k_cls, qn, m->sh_cls.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_cls.grid, cls_lds_bytes(qn, c.dim),
+               m->stream, a);
+}
+void launch_sample(kh_model* m, int advance, int n_forced) {
+  const kh_config& c = m->cfg;
+  KhSampleArgs a;
+  a.part_val = m->part_val;
+  a.part_idx = m->part_idx;
+  a.nparts = m->nparts;
+  a.forced = n_forced > 0 ? m->d_forced : nullptr;
+  a.n_forced = n_forced;
+  a.words = m->d_words;
+  a.words_cap = m->seq_cap;
+  a.d_next = m->d_next;
+  a.d_token = m->d_token;
+  a.d_pos = m->d_pos;
+  a.tok_emb = m->tok_emb;
+  a.x = m->x;
+  a.dim = c.dim;
+  a.vocab = c.vocab_size;
+  a.advance = advance;
+  hipLaunchKernelGGL(k_sample, dim3(1), dim3(KH_WG), 0, m->stream, a);
+}
+
+// one fused decode step = 5L + 2 launches.  ev (optional) receives an event after each launch.
+void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev) {
+  int e = 0;
+  auto mark = [&]() {
+    if (ev) (void)hipEventRecord(ev[e++], m->stream);
+  };
+  mark();
+  for (int l = 0; l < m->cfg.layer_num; ++l) {
+    launch_qkv(m, l);
+    mark();
+    launch_attn(m, l);
+    mark();
+    launch_wo(m, l);
+    mark();
+    launch_ffn13(m, l);
+    mark();
+    launch_w2(m, l);
+    mark();
+  }
+  launch_cls(m);
+  mark();
+  launch_sample(m, advance, n_forced);
+  mark();
+}
+
+// the reference's own launch sequence, one C-ABI op per reference kernel (llama3.cpp:147-167)
+int launch_step_unfused(kh_model* m, int pos) {
+  const kh_config& c = m->cfg;
+  void* s = (void*)m->stream;
+  int rc;
+#define KH_TRY(x)          \
+  if ((rc = (x)) != KH_OK) \
+  return rc
+  auto lin = [&](const KhLin& L, const float* in, float* out, int M, int K) -> int {
+    int r = c.is_quant ? kh_matmul_q8(in, (const int8_t*)L.w, L.scales, c.group_size, out, M, K, s)
+                       : kh_matmul_f32(in, (const float*)L.w, out, M, K, 1.f, s);
+    if (r == KH_OK && L.bias) r = kh_add_f32(out, L.bias, out, K, s);  // matmul.cpp:74-77
+    return r;
+  };
+  for (int l = 0; l < c.layer_num; ++l) {
+    const LayerW& W = m->layers[l];
+    float* krow = m->kcache + ((size_t)l * c.cache_len + pos) * c.kv_dim;
+    float* vrow = m->vcache + ((size_t)l * c.cache_len + pos) * c.kv_dim;
+    KH_TRY(kh_rmsnorm_f32(m->x, W.att_norm, m->rms, c.dim, c.rms_eps, s));
+    KH_TRY(lin(W.wq, m->rms, m->q, c.dim, c.dim));
+    KH_TRY(lin(W.wk, m->rms, krow, c.dim, c.kv_dim));
+    KH_TRY(lin(W.wv, m->rms, vrow, c.dim, c.kv_dim));
+    KH_TRY(kh_rope_f32(c.dim, c.kv_dim, c.head_size, m->q, krow, nullptr, pos, m->sin_cache,
+                       m->cos_cache, c.rope_mode, s));
+    KH_TRY(kh_mha_f32(nullptr, pos, c.head_num, l, c.cache_len, c.kv_dim, c.kv_mul, c.head_size,
+                      m->att, m->q, m->score, m->kcache, m->vcache, s));
+    KH_TRY(lin(W.wo, m->att, m->q /* kAttnOutput aliases kQuery, llama3.cpp:478-489 */, c.dim,
+               c.dim));
+    KH_TRY(kh_add_f32(m->x, m->q, m->x, c.dim, s));
+    KH_TRY(kh_rmsnorm_f32(m->x, W.ffn_norm, m->rms, c.dim, c.rms_eps, s));
+    KH_TRY(lin(W.w1, m->rms, m->h1, c.dim, c.hidden_dim));
+    KH_TRY(lin(W.w3, m->rms, m->h3, c.dim, c.hidden_dim));
+    KH_TRY(kh_swiglu_f32(m->h1, m->h3, m->h1, c.hidden_dim, s));
+    KH_TRY(lin(W.w2, m->h1, m->w2o, c.hidden_dim, c.dim));
+    KH_TRY(kh_add_f32(m->x, m->w2o, m->x, c.dim, s));
+  }
+  KH_TRY(kh_rmsnorm_f32(m->x, m->final_norm, m->x, c.dim, c.rms_eps, s));
+  KH_TRY(lin(m->cls, m->x, m->logits, c.dim, c.vocab_size));
+  KH_TRY(kh_argmax_f32(m->logits, c.vocab_size, m->d_next, s));
+#undef KH_TRY
+  return KH_OK;
+}
+
+void set_state(kh_model* m, int token, int pos) {
+  hipLaunchKernelGGL(k_set_state, dim3(1), dim3(KH_WG), 0, m->stream, token, pos, m->d_token,
+                     m->d_pos, m->tok_emb, m->x, m->cfg.dim);
+}
+
+int ensure_pinned_words(kh_model* m, int n) {
+  for (auto& e : m->ev_chunk)
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipErrorUnknown;
+  if (n <= m->pin_cap) return KH_OK;
+  if (m->h_words_pin) (void)hipHostFree(m->h_words_pin);
+  m->h_words_pin = nullptr;
+  m->pin_cap = 0;
+  if (hipHostMalloc((void**)&m->h_words_pin, sizeof(int32_t) * (size_t)n, hipHostMallocDefault) !=
+      hipSuccess)
+    return (int)hipErrorUnknown;
+  m->pin_cap = n;
+  return KH_OK;
+}
+
+int ensure_seq_cap(kh_model* m, int n) {
+  if (n <= m->seq_cap) return KH_OK;
+  if (m->d_forced) (void)hipFree(m->d_forced);
+  if (m->d_words) (void)hipFree(m->d_words);
+  m->d_forced = m->d_words = nullptr;
+  m->seq_cap = 0;
+  int rc;
+  if ((rc = dalloc(&m->d_forced, (size_t)n + 1)) != KH_OK) return rc;
+  if ((rc = dalloc(&m->d_words, (size_t)n + 1)) != KH_OK) return rc;
+  // forced[i] = -1 (0xFFFFFFFF): every position sampled, until a generate uploads its prompt
+  KH_CHECK_HIP(hipMemsetAsync(m->d_forced, 0xFF, sizeof(int32_t) * ((size_t)n + 1), m->stream));
+  m->seq_cap = n;
+  // the graph captured pointers/capacity: rebuild
+  if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
+  if (m->gexecN) (void)hipGraphExecDestroy(m->gexecN);
+  if (m->graph) (void)hipGraphDestroy(m->graph);
+  if (m->graphN) (void)hipGraphDestroy(m->graphN);
+  m->gexec = m->gexecN = nullptr;
+  m->graph = m->graphN = nullptr;
+  return KH_OK;
+}
+
+int capture_steps(kh_model* m, int n_forced, int steps, hipGraph_t* g, hipGraphExec_t* ge) {
+  KH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < steps; ++i) launch_step_fused(m, /*advance=*/1, n_forced, nullptr);
+  hipError_t e = hipStreamEndCapture(m->stream, g);
+  if (e != hipSuccess) return (int)e;
+  KH_CHECK_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+  return KH_OK;
+}
+int ensure_graph(kh_model* m, int n_forced) {
+  int rc;
+  if (!m->gexec && (rc = capture_steps(m, n_forced, 1, &m->graph, &m->gexec)) != KH_OK) return rc;
+  if (!m->gexecN &&
+      (rc = capture_steps(m, n_forced, KH_GRAPH_STEPS, &m->graphN, &m->gexecN)) != KH_OK)
+    return rc;
+  return KH_OK;
+}
+
+int configure_step_kernels(kh_model* m) {
+  const kh_config& c = m->cfg;
+  // big activation vectors (hidden > 16 K floats) need the >64 KiB dynamic-LDS opt-in
+  const size_t lds_need = fused_lds_bytes(c.is_quant, c.hidden_dim);
+  if (lds_need > 160 * 1024) return KH_ERR_UNSUPPORTED;
+  if (lds_need > 64 * 1024) {
+    const int v = (int)lds_need;
+#define KH_ATTR(Q, UU, SP)                                                                     \
+  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 0, SP>,                             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, v);                    \
+  (void)hipFuncSetAttribute((const void*)k_gemv_res<Q, UU, 6, SP>,                             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, v)
+    KH_ATTR(false, 8, 1); KH_ATTR(false, 8, 2); KH_ATTR(false, 8, 4);
+    KH_ATTR(false, 4, 1); KH_ATTR(false, 4, 2); KH_ATTR(false, 4, 4);
+    KH_ATTR(false, 2, 1); KH_ATTR(false, 2, 2); KH_ATTR(false, 2, 4);
+    KH_ATTR(true, 4, 1); KH_ATTR(true, 4, 2); KH_ATTR(true, 4, 4);
+    KH_ATTR(true, 2, 1); KH_ATTR(true, 2, 2); KH_ATTR(true, 2, 4);
+#undef KH_ATTR
+  }
+  return KH_OK;
+}
+
+}  // namespace khm
+using namespace khm;
+
+extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t is_prompt,
+                                int32_t exec, int32_t* h_next) {
+  if (!m || !h_next) return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if (token < 0 || token >= c.vocab_size || pos < 0 || pos >= c.cache_len) return KH_ERR_RANGE;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  set_state(m, token, pos);  // embedding() + fill_input (llama3.cpp:578-598, model.cpp:245-263)
+  int rc = KH_OK;
+  if (exec == KH_EXEC_UNFUSED) {
+    rc = launch_step_unfused(m, pos);
+  } else if (exec == KH_EXEC_FUSED || exec == KH_EXEC_GRAPH) {
+    launch_step_fused(m, /*advance=*/0, /*n_forced=*/0, nullptr);
+    rc = kh_launch_status();
+  } else {
+    return KH_ERR_INVALID_ARG;
+  }
+  if (rc != KH_OK) return rc;
+  int32_t next = -1;
+  KH_CHECK_HIP(hipMemcpyAsync(&next, m->d_next, sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  *h_next = is_prompt ? -1 : next;  // post_processing (llama3.cpp:733-745)
+  return KH_OK;
+}
+
+extern "C" int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
+                                 int32_t total_steps, int32_t exec, int32_t* h_words,
+                                 int32_t* n_words, float* h_elapsed_ms) {
+  return kh_model_generate_until(m, h_prompt, n_prompt, total_steps, exec, nullptr, 0, h_words,
+                                 n_words, h_elapsed_ms);
+}
+
+namespace {
+inline bool is_stop(int32_t t, const int32_t* stop, int n_stop) {
+  for (int i = 0; i < n_stop; ++i)
+    if (stop[i] == t) return true;
+  return false;
+}
+}  // namespace
+
+extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
+                                       int32_t total_steps, int32_t exec, const int32_t* h_stop,
+                                       int32_t n_stop, int32_t* h_words, int32_t* n_words,
+                                       float* h_elapsed_ms) {
+  if (!m || !h_prompt || n_prompt <= 0 || total_steps <= 0 || !h_words || !n_words ||
+      n_stop < 0 || (n_stop > 0 && !h_stop))
+    return KH_ERR_INVALID_ARG;
+  const kh_config& c = m->cfg;
+  if (total_steps > c.cache_len) return KH_ERR_RANGE;
+  for (int i = 0; i < n_prompt; ++i)
+    if (h_prompt[i] < 0 || h_prompt[i] >= c.vocab_size) return KH_ERR_RANGE;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  int rc;
+  *n_words = 0;
+
+  if (exec == KH_EXEC_UNFUSED) {
+    // the reference loop verbatim: host drives every step and reads `next` back each time
+    KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+    int pos = 0, next = -1, nw = 0;
+    while (pos < total_steps) {
+      const bool is_prompt = pos < n_prompt - 1;
+      const int tok = pos <= n_prompt - 1 ? h_prompt[pos] : next;
+      int got = -1;
+      if ((rc = kh_model_predict(m, tok, pos, is_prompt, KH_EXEC_UNFUSED, &got)) != KH_OK) return rc;
+      // demo/main.cpp:30-32: only a sampled token can end the sentence (next == -1 in the prompt)
+      if (!is_prompt && is_stop(got, h_stop, n_stop)) break;
+      next = is_prompt ? h_prompt[pos + 1] : got;
+      h_words[nw++] = next;
+      pos += 1;
+    }
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+    KH_CHECK_HIP(hipEventSynchronize(m->ev1));
+    if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
+    *n_words = nw;
+    return KH_OK;
+  }
+  if (exec != KH_EXEC_GRAPH && exec != KH_EXEC_FUSED) return KH_ERR_INVALID_ARG;
+
+  if ((rc = ensure_seq_cap(m, total_steps)) != KH_OK) return rc;
+  // forced[i] = token fed at position i while inside the prompt, -1 afterwards
+  std::vector<int32_t> forced((size_t)m->seq_cap + 1, -1);
+  for (int i = 0; i < n_prompt && i <= m->seq_cap; ++i) forced[i] = h_prompt[i];
+  KH_CHECK_HIP(hipMemcpyAsync(m->d_forced, forced.data(), forced.size() * sizeof(int32_t),
+                              hipMemcpyHostToDevice, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));  // `forced` is a stack-lifetime staging buffer
+  const int n_forced = m->seq_cap + 1;
+  if (exec == KH_EXEC_GRAPH && (rc = ensure_graph(m, n_forced)) != KH_OK) return rc;
+
+  // prompt phase: the tokens that are only fed (positions 0 .. n_prompt-2).  KH_PREFILL selects how:
+  //   "0" / "token"  the reference's one forward pass per prompt token (demo/main.cpp:20-22)
+  //   "gemv"         B-token VALU kernels: K/V rows bit-identical to the token-by-token ones
+  //   "gemm"         fp32-MFMA GEMM prefill: rows equal to fp32 round-off (tolerance, NOT bit-identity:
+  //                  greedy tokens can differ from the token-by-token path at near-ties)
+  //   unset          "gemm" from KH_PG_MIN_TOKENS fed-only tokens on, "gemv" below that
+  // any other value is an error (KH_ERR_INVALID_ARG), not a silent choice.
+  int start = 0;
+  KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
+  if (n_prompt - 1 >= 2 && n_prompt - 1 < total_steps) {
+    const char* e = getenv("KH_PREFILL");
+    bool want_gemm = n_prompt - 1 >= KH_PG_MIN_TOKENS, want_gemv = true;
+    if (e && *e) {
+      if (!strcmp(e, "0") || !strcmp(e, "token")) want_gemm = want_gemv = false;
+      else if (!strcmp(e, "gemv")) want_gemm = false;
+      else if (!strcmp(e, "gemm")) want_gemm = true;
+      else return KH_ERR_INVALID_ARG;
+    }
+    if (want_gemm && pg_supported(m)) {
+      if ((rc = kh_model_prefill_gemm(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
+      start = n_prompt - 1;
+    } else if (want_gemv && prefill_supported(m)) {
+      if ((rc = kh_model_prefill(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
+      start = n_prompt - 1;
+    }
+  }
+  set_state(m, h_prompt[start], start);
+  auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps
+    if (exec == KH_EXEC_GRAPH) {
+      if (total_steps - s >= KH_GRAPH_STEPS) {
+        if (hipGraphLaunch(m->gexecN, m->stream) != hipSuccess) return -1;
+        return KH_GRAPH_STEPS;
+      }
+      if (hipGraphLaunch(m->gexec, m->stream) != hipSuccess) return -1;
+      return 1;
+    }
+    launch_step_fused(m, 1, n_forced, nullptr);
+    return 1;
+  };
+  int n_out = total_steps;
+  if (n_stop == 0) {
+    for (int s = start; s < total_steps;) {
+      const int n = launch_chunk(s);
+      if (n < 0) return (int)hipErrorUnknown;
+      s += n;
+    }
+    KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
+    if ((rc = kh_launch_status()) != KH_OK) return rc;
+    KH_CHECK_HIP(hipMemcpyAsync(h_words, m->d_words, sizeof(int32_t) * total_steps,
+                                hipMemcpyDeviceToHost, m->stream));
+    KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < start; ++i) h_words[i] = h_prompt[i + 1];  // forced, main.cpp:36-38
+  } else {
+    // Stop-token check without a per-step host round trip: the words of every
+    // chunk of steps are mirrored into pinned memory behind the chunk, and the host inspects
+    // chunk k while chunk k+1 is already queued, so the GPU never waits for the check.  At
+    // most two chunks of steps run past the stop token; their words are discarded.
+    if ((rc = ensure_pinned_words(m, total_steps)) != KH_OK) return rc;
+    struct Chunk { int s0, n; };
+    Chunk infl[2];
+    int n_infl = 0, head = 0, launched = start, stop_at = -1;
+    for (int i = 0; i < start; ++i) m->h_words_pin[i] = h_prompt[i + 1];
+    // Once chunks are queued, an early return must not leave graph launches and their D2H copies
+    // into h_words_pin in flight (the caller may destroy the model or start another generate that
+    // reallocates those buffers): every error path below drains the stream first.
+    auto fail = [&](int code) -> int {
+      (void)hipStreamSynchronize(m->stream);
+      return code;
+    };
+#define KH_CHECK_DRAIN(expr)                          \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return fail((int)_e);       \
+  } while (0)
+    while (stop_at < 0 && (launched < total_steps || n_infl > 0)) {
+      while (launched < total_steps && n_infl < 2) {
+        const int n = launch_chunk(launched);
+        if (n < 0) return fail((int)hipErrorUnknown);
+        const int slot = (head + n_infl) & 1;
+        KH_CHECK_DRAIN(hipMemcpyAsync(m->h_words_pin + launched, m->d_words + launched,
+                                      sizeof(int32_t) * n, hipMemcpyDeviceToHost, m->stream));
+        KH_CHECK_DRAIN(hipEventRecord(m->ev_chunk[slot], m->stream));
+        infl[slot] = {launched, n};
+        launched += n;
+        ++n_infl;
+      }
+      KH_CHECK_DRAIN(hipEventSynchronize(m->ev_chunk[head]));
+      const Chunk c0 = infl[head];
+      for (int s = c0.s0; s < c0.s0 + c0.n; ++s)
+        if (s >= n_prompt - 1 && is_stop(m->h_words_pin[s], h_stop, n_stop)) {
+          stop_at = s;
+          break;
+        }
+      if (stop_at >= 0) {
+        // elapsed_ms ends behind the chunks already queued when the stop token was seen: it
+        // includes up to 2 x 8 discarded steps past the stop (the reference's timer ends with the
+        // step that produced it)
+        KH_CHECK_DRAIN(hipEventRecord(m->ev1, m->stream));
+      }
+      head ^= 1;
+      --n_infl;
+    }
+    if (stop_at < 0) KH_CHECK_DRAIN(hipEventRecord(m->ev1, m->stream));
+    if ((rc = kh_launch_status()) != KH_OK) return fail(rc);
+#undef KH_CHECK_DRAIN
+    KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    n_out = stop_at >= 0 ? stop_at : total_steps;
+    memcpy(h_words, m->h_words_pin, sizeof(int32_t) * (size_t)n_out);
+  }
+  if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
+  *n_words = n_out;
+  return KH_OK;
+}

@@ -3,7 +3,7 @@
 //
 // These are the literal drop-ins for kernel::get_*_kernel(kDeviceHIP): same argument
 // meaning as the reference's CUDA kernels, raw device pointers instead of tensor::Tensor.
-// The fused decode path (kh_model.hip) reuses the same device cores (kh_gemv.h, kh_attn.h).
+// The fused decode path (kh_model_step.hip) reuses the same device cores (kh_gemv.h, kh_attn.h).
 #include "kh_attn.h"
 #include "kh_common.h"
 #include "kh_gemv.h"
@@ -518,7 +518,7 @@ extern "C" int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
 }
 
 // Decode attention with the long-context time split (the kernel the fused step launches).
-// Split geometry of the decode launch for a cache of seq_len rows (mirrors kh_model.hip).
+// Split geometry of the decode launch for a cache of seq_len rows (mirrors kh_model_load.hip::finish_create).
 static void mha_decode_geometry(int head_num, int kv_mul, int head_size, int seq_len, int* ns,
                                 int* ns_g, int* stride, int* t_long) {
   *ns = head_size > 32 ? attn_num_splits(seq_len) : 1;

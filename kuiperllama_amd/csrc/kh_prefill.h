@@ -304,7 +304,7 @@ struct KhPfTokens {
   int32_t t[KH_PF_BMAX];
 };
 // embedding rows of the B tokens -> X[B][dim]   (emb_kernel.cu / model.cpp:245-263 fill_input)
-__global__ __launch_bounds__(KH_WG) void k_pf_embed(KhPfTokens tok, const float* __restrict__ emb,
+static __global__ __launch_bounds__(KH_WG) void k_pf_embed(KhPfTokens tok, const float* __restrict__ emb,
                                                     float* __restrict__ X, int dim) {
   const int b = blockIdx.x;
   const f32x4* src = (const f32x4*)(emb + (size_t)tok.t[b] * dim);

@@ -16,8 +16,8 @@
 //   * decoding = concatenate pieces, control pieces vanish, byte pieces re-form UTF-8,
 //     U+2581 -> ' ', the dummy-prefix space is dropped.
 // Pinned against the sentencepiece Python package on models trained in-container
-// (tests/golden/make_spm_golden.py, tests/test_tokenizer.py).  Llama-3 / Qwen byte-level BPE
-// (encode.cpp:59-180, tiktoken.h) is not covered.
+// (tests/golden/make_spm_golden.py, tests/test_tokenizer.py).  The Llama-3 / Qwen byte-level BPE
+// (encode.cpp:59-180, tiktoken.h) lives in kh_bpe.cpp.
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>

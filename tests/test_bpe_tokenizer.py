@@ -109,3 +109,23 @@ def test_fuzz_against_hf_tokenizers(name):
         assert got == want, (name, "ref", repr(s), got, want)
         assert plain.decode(plain.encode(s, bos=False)) == s
         assert ref.decode(got) == s.replace("Ġ", " ")
+
+
+def test_truncated_tokenizer_json_is_rejected_not_overread():
+    """kh_bpe_create_from_memory takes (ptr, nbytes) - not a NUL-terminated string.  A file cut
+    anywhere (inside a number, right behind a ':', inside a string) must come back as an error;
+    the integer parser is bounded by the buffer end (strtol could read past it)."""
+    import numpy as np
+    from kuiperllama_amd import _ffi
+    from kuiperllama_amd.tokenizer import BpeTokenizer, LLAMA3
+    data = open(os.path.join(GOLDEN, "bpe_llama3_like.json"), "rb").read()
+    assert BpeTokenizer.from_bytes(data, LLAMA3).vocab_size > 0
+    rng = np.random.default_rng(0)
+    cuts = sorted(set(int(c) for c in rng.integers(1, len(data) - 1, 150)))
+    # plus cuts that end exactly inside / right before a vocabulary id
+    import re
+    for m in list(re.finditer(rb'": \d+', data))[:40]:
+        cuts += [m.start() + 3, m.start() + 4, m.end() - 1]
+    for c in cuts:
+        with pytest.raises(_ffi.KhError):
+            BpeTokenizer.from_bytes(data[:c], LLAMA3)

@@ -222,7 +222,7 @@ def test_loader_entry_points_agree(gpu):
 
 def test_chunked_pinned_upload_is_byte_exact(gpu):
     """Images larger than one 64 MiB staging chunk go through the double-buffered pinned
-    uploader (kh_model.hip::upload_chunked); the arena must equal a direct device image."""
+    uploader (kh_model_load.hip::upload_chunked); the arena must equal a direct device image."""
     from kuiperllama_amd.model import KuiperModel
     spec = binfmt.ModelSpec(512, 1408, 8, 8, 8, 32000, 128, True, binfmt.FAMILY_LLAMA, False, 64,
                             binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "upload-168MB")
@@ -625,9 +625,17 @@ def test_generate_long_prompt_takes_gemm_prefill(gpu, oracle, name, monkeypatch)
     got, _ = m.generate(prompt, steps)
     if got != want:
         _fail_with_margin(oracle, img_h, spec, prompt, got, want)
-    for mode in ("gemm", "gemv", "0"):
+    for mode in ("gemm", "gemv", "0", "token"):
         monkeypatch.setenv("KH_PREFILL", mode)
         assert m.generate(prompt, steps)[0] == want, mode
+    # an unknown value is an error, not a silent choice of path (it used to select "gemv")
+    from kuiperllama_amd import _ffi
+    monkeypatch.setenv("KH_PREFILL", "1")
+    with pytest.raises(_ffi.KhError) as ei:
+        m.generate(prompt, steps)
+    assert ei.value.code == -1
+    monkeypatch.delenv("KH_PREFILL")
+    assert m.generate(prompt, steps)[0] == want
     m.close()
 
 

@@ -46,7 +46,7 @@ struct Args {
   const float* x; const float* wn; float* out; int M, pairs, paired;    // paired: rows (r, r) of (wa, wb); else rows (2p, 2p+1) of wa
 };
 
-template <int RUNG, int U, int SPLIT, bool NORM, int MAXV, int DEPTH, bool ROLL>
+template <int RUNG, int U, int SPLIT, bool NORM, int MAXV>
 __global__ __launch_bounds__(KH_WG_MAX) void k_ladder(const Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -73,19 +73,19 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_ladder(const Args a) {
       fold += s0 + s1;
     }
   };
-  gemv_pairs<SPLIT, DEPTH, ROLL>(g, xs, a.pairs, lane, red + KH_WAVES_MAX, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<SPLIT>(g, xs, a.pairs, lane, red + KH_WAVES_MAX, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                     [&]() __attribute__((always_inline)) { if (RUNG >= 1) st.issue(); },
                     [&]() __attribute__((always_inline)) { if (RUNG >= 1) st.finish(xs, 1e-5f, red); else __syncthreads(); }, epi);
   if (RUNG < 4 && fold == 123.456f) out[0] = fold;
 }
 
-template <int RUNG, int U, int SPLIT, bool NORM, int MAXV, int DEPTH, bool ROLL>
+template <int RUNG, int U, int SPLIT, bool NORM, int MAXV>
 static float run(hipStream_t S, const Args* args, int NL, int grid, int wg, size_t lds) {
   if (lds > 64 * 1024)
-    CK(hipFuncSetAttribute((const void*)k_ladder<RUNG, U, SPLIT, NORM, MAXV, DEPTH, ROLL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)k_ladder<RUNG, U, SPLIT, NORM, MAXV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipGraph_t g; hipGraphExec_t ge;
   CK(hipStreamBeginCapture(S, hipStreamCaptureModeThreadLocal));
-  for (int l = 0; l < NL; ++l) hipLaunchKernelGGL((k_ladder<RUNG, U, SPLIT, NORM, MAXV, DEPTH, ROLL>), dim3(grid), dim3(wg), lds, S, args[l]);
+  for (int l = 0; l < NL; ++l) hipLaunchKernelGGL((k_ladder<RUNG, U, SPLIT, NORM, MAXV>), dim3(grid), dim3(wg), lds, S, args[l]);
   CK(hipStreamEndCapture(S, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   CK(hipGraphLaunch(ge, S)); CK(hipStreamSynchronize(S));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -98,12 +98,12 @@ static float run(hipStream_t S, const Args* args, int NL, int grid, int wg, size
   return best * 1e3f / NL;
 }
 
-template <int U, int SPLIT, bool NORM, int MAXV, int DEPTH = 1, bool ROLL = true>
+template <int U, int SPLIT, bool NORM, int MAXV>
 static void ladder(hipStream_t S, const char* name, const Args* args, int NL, int grid, int wg, size_t lds, double bytes) {
-  const float t[5] = {run<0, U, SPLIT, NORM, MAXV, DEPTH, ROLL>(S, args, NL, grid, wg, lds), run<1, U, SPLIT, NORM, MAXV, DEPTH, ROLL>(S, args, NL, grid, wg, lds),
-                      run<2, U, SPLIT, NORM, MAXV, DEPTH, ROLL>(S, args, NL, grid, wg, lds), run<3, U, SPLIT, NORM, MAXV, DEPTH, ROLL>(S, args, NL, grid, wg, lds),
-                      run<4, U, SPLIT, NORM, MAXV, DEPTH, ROLL>(S, args, NL, grid, wg, lds)};
-  printf("%-6s wg%d grid%-4d U%d split%d depth%d %s |", name, wg, grid, U, SPLIT, DEPTH, ROLL ? "roll" : "bulk");
+  const float t[5] = {run<0, U, SPLIT, NORM, MAXV>(S, args, NL, grid, wg, lds), run<1, U, SPLIT, NORM, MAXV>(S, args, NL, grid, wg, lds),
+                      run<2, U, SPLIT, NORM, MAXV>(S, args, NL, grid, wg, lds), run<3, U, SPLIT, NORM, MAXV>(S, args, NL, grid, wg, lds),
+                      run<4, U, SPLIT, NORM, MAXV>(S, args, NL, grid, wg, lds)};
+  printf("%-6s wg%d grid%-4d U%d split%d |", name, wg, grid, U, SPLIT);
   for (int r = 0; r < 5; ++r) printf(" %6.2f (%.3f)", t[r], bytes / (t[r] * 1e-6) / 8e12);
   printf("\n");
   fflush(stdout);
@@ -134,11 +134,7 @@ int main() {
   };
   const size_t lds_dim = kh_q8_lds_bytes(dim) + 3 * KH_WAVES_MAX * sizeof(float);
   const size_t lds_hid = kh_q8_lds_bytes(hidden) + 3 * KH_WAVES_MAX * sizeof(float);
-#define VARIANTS(NAME, UU, SP, NORM, MV, GRID, WG, LDS, B)                    \
-  ladder<UU, SP, NORM, MV, 1, true>(S, NAME, args, NL, GRID, WG, LDS, B);     \
-  ladder<UU, SP, NORM, MV, 1, false>(S, NAME, args, NL, GRID, WG, LDS, B);    \
-  ladder<UU, SP, NORM, MV, 2, true>(S, NAME, args, NL, GRID, WG, LDS, B);     \
-  ladder<UU, SP, NORM, MV, 2, false>(S, NAME, args, NL, GRID, WG, LDS, B);
+#define VARIANTS(NAME, UU, SP, NORM, MV, GRID, WG, LDS, B) ladder<UU, SP, NORM, MV>(S, NAME, args, NL, GRID, WG, LDS, B);
   {
     const double b = fill(2 * (size_t)hidden, dim, 1) + 2.0 * dim * 4 + hidden * 4.0;
     for (int grid : {512, 1024}) { VARIANTS("ffn13", 4, 1, true, 4, grid, 256, lds_dim, b) }
@@ -160,10 +156,6 @@ int main() {
     for (int grid : {256, 512}) { VARIANTS("w2", 4, 4, false, 6, grid, 512, lds_hid, b) }
     for (int grid : {256, 512}) { VARIANTS("w2-mv0", 4, 4, false, 0, grid, 512, lds_hid, b) }
     for (int grid : {256, 512}) { VARIANTS("w2", 4, 2, false, 6, grid, 512, lds_hid, b) }
-  }
-  {
-    const double b = fill((size_t)32000, dim, 0) + 2.0 * dim * 4 + 32000 * 4.0;
-    for (int grid : {512, 768}) { VARIANTS("cls", 4, 1, true, 4, grid, 256, lds_dim, b) }
   }
   return 0;
 }
