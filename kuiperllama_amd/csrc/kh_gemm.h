@@ -43,13 +43,6 @@
 #include "kh_fused.h"
 
 #define KH_PG_TMAX 128           // prompt tokens per weight pass (8 MFMA token tiles)
-// ablation switches (tools/exp_gemm.sh builds variants that compute WRONG results on purpose):
-#ifndef KH_PG_EXP_NOA
-#define KH_PG_EXP_NOA 0          // weight operand loaded once per wave instead of streamed
-#endif
-#ifndef KH_PG_EXP_NOB
-#define KH_PG_EXP_NOB 0          // activation operand loaded once per wave instead of streamed
-#endif
 // Workgroup width: <= 8 waves.  The fp32 shapes use 4 (ONE wave per SIMD, see pg_shape); int8 up to 8
 // (its dequant VALU work wants a partner wave on the SIMD to keep the matrix pipe busy).
 #define KH_PG_WG_MAX_F32 512
@@ -153,28 +146,17 @@ __device__ __forceinline__ void pg_kloop_f32(const float* const (&wrow)[R], cons
   f32x4 a[2][RING][R];
   f32x4 xb[2][NT];
   const int last = b1 - 1;
-  bool first_a = true, first_b = true;
   auto load_a = [&](int ring, int base) __attribute__((always_inline)) {
-    if (KH_PG_EXP_NOA && !first_a) return;
 #pragma unroll
     for (int d = 0; d < RING; ++d) {
       const int bb = base + d < last ? base + d : last;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        a[ring][d][r] = ld_nt((const f32x4*)(wrow[r] + (size_t)bb * 16));
-        if (KH_PG_EXP_NOA) a[1 - ring][d][r] = a[ring][d][r];
-      }
+      for (int r = 0; r < R; ++r) a[ring][d][r] = ld_nt((const f32x4*)(wrow[r] + (size_t)bb * 16));
     }
-    first_a = false;
   };
   auto load_b = [&](int set, int bb, int) __attribute__((always_inline)) {
-    if (KH_PG_EXP_NOB && !first_b) return;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      xb[set][nt] = *(const f32x4*)(B.base + nt * B.s_nt + (size_t)bb * B.s_b);
-      if (KH_PG_EXP_NOB) xb[1 - set][nt] = xb[set][nt];
-    }
-    first_b = false;
+    for (int nt = 0; nt < NT; ++nt) xb[set][nt] = *(const f32x4*)(B.base + nt * B.s_nt + (size_t)bb * B.s_b);
   };
   auto sub = [&](int ph, int d, int, int set) __attribute__((always_inline)) {
 #pragma unroll
@@ -186,6 +168,49 @@ __device__ __forceinline__ void pg_kloop_f32(const float* const (&wrow)[R], cons
           acc[r][nt] = mfma16(pg_comp(a[ph][d][r], c), pg_comp(xb[set][nt], c), acc[r][nt]);
   };
   pg_phases<RING, 1>(b0, b1, load_a, load_b, sub);
+}
+
+// Uniform ring (small register tiles): weights AND activations of block b + D are requested together
+// when block b has been consumed, D blocks ahead of their use.  With both operand streams at the same
+// distance the in-order vmcnt couples nothing: the wait for block b leaves (D - 1) x (R + NT) loads in
+// flight, and D x (MFMA time of a block) covers the HBM latency of the weights as well as the L2
+// latency of the activations.  The phase scheme above prefetches the activations ONE step ahead -
+// enough when a step holds >= 64 MFMAs (R x NT = 16), far too little for the 16-MFMA steps of the
+// (1,4) / (2,2) tiles the small-M GEMMs (wo, w2, QKV) need to fill the chip (0.24 us per step against
+// ~0.5 us of L2 latency: MfmaUtil 28-33 % in round 2).  Needs (b1 - b0) % D == 0 and >= 2 D blocks;
+// D * (R + NT) float4 of ring registers.
+template <int R, int NT, int D>
+__device__ __forceinline__ void pg_kloop_f32_ring(const float* const (&wrow)[R], const PgBAddr& B, int b0,
+                                                  int b1, f32x4 (&acc)[R][NT]) {
+  f32x4 a[D][R];
+  f32x4 xb[D][NT];
+  auto load = [&](int slot, int bb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[slot][r] = ld_nt((const f32x4*)(wrow[r] + (size_t)bb * 16));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xb[slot][nt] = *(const f32x4*)(B.base + nt * B.s_nt + (size_t)bb * B.s_b);
+    __builtin_amdgcn_sched_barrier(0);  // slots stay in issue order (vmcnt retires in order)
+  };
+  auto mfma = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[r][nt] = mfma16(pg_comp(a[slot][r], c), pg_comp(xb[slot][nt], c), acc[r][nt]);
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) load(d, b0 + d);
+  for (int b = b0; b < b1 - D; b += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      mfma(d);
+      load(d, b + d + D);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) mfma(d);  // drain: the last D blocks, nothing left to request
 }
 
 // int8 group-64 weights: blocks of 64 columns.  Lane (i, h) owns the 16 weights
@@ -295,7 +320,17 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
     } else {
       B = PgBAddr{a.B + (size_t)(tok0 + i) * K + 4 * h, (size_t)16 * K, 16, 0};
     }
-    if (b1 > b0) pg_kloop_f32<R, NT>(wrow, B, b0, b1, acc);
+    // small register tiles take the uniform ring (both operands D blocks ahead) when the wave's block
+    // count allows it; the big (2, 8) tile - 64 MFMAs per step - keeps the phase scheme
+    constexpr int RING_D = R * NT <= 8 ? 8 : 0;
+    if constexpr (RING_D > 0) {
+      if (b1 - b0 >= 2 * RING_D && (b1 - b0) % RING_D == 0)
+        pg_kloop_f32_ring<R, NT, RING_D>(wrow, B, b0, b1, acc);
+      else if (b1 > b0)
+        pg_kloop_f32<R, NT>(wrow, B, b0, b1, acc);
+    } else if (b1 > b0) {
+      pg_kloop_f32<R, NT>(wrow, B, b0, b1, acc);
+    }
   } else {
     const int nb = K >> 6;
     const int b0 = __builtin_amdgcn_readfirstlane((int)((long)kpart * nb / ks));
