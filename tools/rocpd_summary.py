@@ -38,6 +38,10 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--workload", default="llama3.2-1b")
+    ap.add_argument("--commit", default=os.environ.get("KH_COMMIT", ""),
+                    help="commit the counters were collected on (stamped into pmc_traffic.json)")
+    ap.add_argument("--command", default="tools/profile_round3.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
+                                         "--kernel-trace -- python tools/pmc_workload.py <workload> --steps 8")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -95,6 +99,9 @@ def main():
             v["hbm_bytes"] = v.get("read_bytes", 0.0) + v.get("write_bytes_uncalibrated", 0.0)
             v["note"] = "per launch; read side = FETCH_SIZE KiB x1024 x2 (gfx950 correction)"
             old[k] = v
+        old["_meta"] = {"commit": a.commit or None, "command": a.command,
+                        "note": "HBM bytes per launch from separate rocprofv3 PMC passes; bench.py reads "
+                                "roofline.traffic from this file (it is NOT measured inside a bench run)"}
         json.dump(old, open(tp, "w"), indent=1, sort_keys=True)
         print("wrote", tp)
 
