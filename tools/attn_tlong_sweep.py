@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 img = binfmt.synth_image(spec, seed=1234, device=dev)
 torch.cuda.synchronize()
 poss = [p for p in (1023, 2047, 4095, 8191, 16383, 32767, 65535, 131071) if p < spec.seq_len]
-for tl in ("0", "2048", "4096", "8192", "16384", "32768"):
+for tl in os.environ.get("KH_SWEEP_TLONGS", "0,2048,4096,8192,16384,32768").split(","):
     os.environ["KH_ATTN_TLONG"] = tl
     m = KuiperModel.from_device_image(img, spec)
     gen = torch.Generator(device=dev)
