@@ -22,6 +22,12 @@
 #include "kh_common.h"
 #include "kh_gemv.h"
 
+// Refill policy of gemv_pairs per kernel (same-box A/B of all four combinations on four models,
+// profiles/r3_roll_vs_bulk_ab.txt): the slot-by-slot ROLLING refill pays only in the int8 QKV kernel
+// (10.9 vs 11.7 us; three short items per wave, dequant-heavy); everywhere else requesting the next
+// tile in one burst after the FMAs is as fast or faster (fp32 ffn13 21.4 vs 21.9 us, Llama-2-7B fp32
+// w2 30.4 vs 32.4) - longer bursts per DRAM row.
+
 
 template <bool QUANT>
 __device__ __forceinline__ float* lds_red_ptr(f32x4* xs, int M) {
@@ -55,8 +61,11 @@ struct KhQkvArgs {
   float eps;
 };
 
+// __launch_bounds__(512, 4): at least 4 waves per SIMD, i.e. at most 128 VGPRs.  The long-row shapes run
+// two 512-thread workgroups per CU (16 waves); the fp32 U = 8 kernels sit at 120-130 registers and a
+// build that crossed 128 lost the second workgroup (w2 fp32 11.8 -> 12.5 us, profiles/r3_aux_first_ab.txt).
 template <bool QUANT, int U, int MAXV, int SPLIT>
-__global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX, 4) void k_qkv(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // Every kernel argument used inside the lambdas is first copied into a scalar local: a
   // lambda that captures the argument STRUCT by reference keeps the whole struct addressable
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_qkv(const KhQkvArgs a) {
     dst[r0] = s0;
     dst[r1] = s1;
   };
-  gemv_pairs<SPLIT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre,
+  gemv_pairs<SPLIT, /*ROLL=*/QUANT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre,
                               [&]() __attribute__((always_inline)) { st.issue(); },
                               [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi);
 }
@@ -174,7 +183,7 @@ struct KhGemvResArgs {
   int M, K, gshift;
 };
 template <bool QUANT, int U, int MAXV, int SPLIT>
-__global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX, 4) void k_gemv_res(const KhGemvResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // scalar locals for everything the lambdas touch (see qkv_body)
   const void* const w = a.w.w;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_gemv_res(const KhGemvResArgs a) {
     x[2 * p] = r.x0 + s0;
     x[2 * p + 1] = r.x1 + s1;
   };
-  gemv_pairs<SPLIT>(
+  gemv_pairs<SPLIT, /*ROLL=*/false>(
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
@@ -212,7 +221,7 @@ struct KhFfn13Args {
   float eps;
 };
 template <bool QUANT, int U, int MAXV>
-__global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
+__global__ __launch_bounds__(KH_WG_MAX, 4) void k_ffn13(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_ffn13(const KhFfn13Args a) {
   auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane == 0) a.h[r] = swiglu1(s0, s1);
   };
-  gemv_pairs<1>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<1, /*ROLL=*/false>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
                        [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
 }
@@ -240,7 +249,7 @@ struct KhClsArgs {
   float eps;
 };
 template <bool QUANT, int U, int MAXV>
-__global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
+__global__ __launch_bounds__(KH_WG_MAX, 4) void k_cls(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_cls(const KhClsArgs a) {
       amax_merge(bv, bi, s1, r1);
     }
   };
-  gemv_pairs<1>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
+  gemv_pairs<1, /*ROLL=*/false>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
                           [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
                        [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);

@@ -229,11 +229,12 @@ struct Gemv<true, U> {
 // one wave per pair leaves 4 waves per CU and no load/compute overlap.  comb = LDS float[8].
 // G: the matrix view - Gemv<QUANT, U>, or any class with its interface (kU, Regs, Rows, Mc, load,
 // load1, fma, fma1; tools/mb_gemv_ladder.hip plugs in stream-only views to price each ingredient).
+// ROLL: refill the tile slot by slot (slot u of the next tile requested right after slot u was consumed)
+// or in one burst after the tile's FMAs; chosen per kernel from same-box A/Bs (kh_fused.h).
 // Measured and not kept (profiles/r3_gemv_ladder_depth_roll.txt, commit 0f6b0a3^): a second register
 // tile requested in the prologue as well (two work items in flight per wave) - no gain on any
-// Llama-2-7B int8 shape, +70 VGPRs; and "consume the tile, then request the next" instead of the
-// slot-by-slot refill - equal within noise.
-template <int SPLIT, class G, class PairFn, class PreFn, class IssueFn, class FinishFn, class EpiFn>
+// Llama-2-7B int8 shape, +70 VGPRs.
+template <int SPLIT, bool ROLL, class G, class PairFn, class PreFn, class IssueFn, class FinishFn, class EpiFn>
 __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int total, int lane,
                                            float* comb, PairFn&& PAIR, PreFn&& PRE, IssueFn&& ISSUE,
                                            FinishFn&& FINISH, EpiFn&& EPI) {
@@ -313,21 +314,33 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
     const int pn = last ? p + np : p;
     const int cn = last ? cb : c1;
     const bool more = pn < total;  // the wave has a following tile (implies valid)
+    auto aux_next = aux;
     if (more) {
       typename G::Rows nxt = cur;
-      if (last) nxt = PAIR(pn);
+      if (last) {
+        nxt = PAIR(pn);
+        // epilogue operands of the next pair (bias, sin/cos, residual): requested AHEAD of its tile.
+        // They are vector loads (the kernel has stored by now, so no scalar-cache path), and the
+        // loop-carried copy of them at the latch waits for them: behind the tile they were the
+        // youngest loads in the in-order queue and that wait was a vmcnt(0) drain of the whole next
+        // tile in every iteration of k_qkv / k_gemv_res (rounds 1-2 and the first rolling version).
+        aux_next = PRE(pn);
+      }
+      if constexpr (ROLL) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        g.fma1(regs, xs, c0, ce, lane, u, a0, a1);
-        g.load1(regs, nxt, cn, ce, lane, u);
+        for (int u = 0; u < U; ++u) {
+          g.fma1(regs, xs, c0, ce, lane, u, a0, a1);
+          g.load1(regs, nxt, cn, ce, lane, u);
+        }
+      } else {
+        g.fma(regs, xs, c0, ce, lane, a0, a1);
+        g.load(regs, nxt, cn, ce, lane);
       }
       cur = nxt;
     } else if (valid) {
       g.fma(regs, xs, c0, ce, lane, a0, a1);
     }
     if (last) {
-      auto aux_next = aux;
-      if (more) aux_next = PRE(pn);  // epilogue operands of the next pair: requested behind its tile
       finish_item(p, valid, a0, a1, aux);
       aux = aux_next;
       a0 = a1 = 0.f;

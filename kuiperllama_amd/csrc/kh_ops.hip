@@ -104,7 +104,7 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_f32(const float* __restrict__ 
     y[r0] = s0 * scale;
     if (r1 != r0) y[r1] = s1 * scale;
   };
-  gemv_pairs<1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<1, /*ROLL=*/false>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
 }
 
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_q8(const float* __restrict__ x
     y[r0] = s0;
     if (r1 != r0) y[r1] = s1;
   };
-  gemv_pairs<1>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<1, /*ROLL=*/false>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                       [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
 }
 

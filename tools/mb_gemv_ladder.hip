@@ -73,7 +73,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_ladder(const Args a) {
       fold += s0 + s1;
     }
   };
-  gemv_pairs<SPLIT>(g, xs, a.pairs, lane, red + KH_WAVES_MAX, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
+  gemv_pairs<SPLIT, true>(g, xs, a.pairs, lane, red + KH_WAVES_MAX, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                     [&]() __attribute__((always_inline)) { if (RUNG >= 1) st.issue(); },
                     [&]() __attribute__((always_inline)) { if (RUNG >= 1) st.finish(xs, 1e-5f, red); else __syncthreads(); }, epi);
   if (RUNG < 4 && fold == 123.456f) out[0] = fold;
