@@ -6,7 +6,7 @@ timeout 2400 python -m pytest tests -m gpu -q --timeout=900 > $O/r3_pytest_gpu.t
 echo "pytest rc=$?" >> $O/r3_pytest_gpu.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r3_smoke.txt 2>&1
 echo "smoke rc=$?" >> $O/r3_smoke.txt
-/usr/bin/time -v timeout 900 python bench.py > $O/r3_bench.json 2> $O/r3_bench.err
+timeout 900 python bench.py > $O/r3_bench.json 2> $O/r3_bench.err
 echo "bench rc=$?" >> $O/r3_bench.err
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/r3_bench_steps20.json 2> $O/r3_bench_steps20.err
-tail -4 $O/r3_pytest_gpu.txt; tail -2 $O/r3_smoke.txt; grep -E "Elapsed|bench rc" $O/r3_bench.err; head -c 400 $O/r3_bench.json
+tail -4 $O/r3_pytest_gpu.txt; tail -2 $O/r3_smoke.txt; grep -E "bench rc" $O/r3_bench.err; head -c 400 $O/r3_bench.json
