@@ -48,6 +48,21 @@ __global__ __launch_bounds__(512) void k_stream(const char* __restrict__ w, cons
   if (acc == 123.456f) out[0] = acc;
 }
 
+// pseudo-random fill (xorshift per 16-byte word): data-dependent effects (DRAM toggling, power) are part
+// of what the real kernels see; a constant fill flatters the floor
+__global__ void k_fill(unsigned* p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u ^ seed;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    p[i] = x;
+  }
+}
+
+__global__ void k_fix_scales(unsigned* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = (p[i] & 0x007fffffu) | 0x3B800000u;
+}
+
 struct Shape { const char* name; int rows, rowbytes; double extra_bytes; };
 
 template <int U, int SPLIT>
@@ -70,7 +85,9 @@ static float run(hipStream_t S, const char* w, const float* sc, size_t slab, siz
   return best * 1e3f / NL;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool random_fill = argc > 1 && argv[1][0] == 'r';
+  printf("fill: %s\n", random_fill ? "pseudo-random bytes, scales in [2^-8, 2^-7)" : "constant (weights 0x01, scales 0)");
   hipStream_t S; CK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
   // Llama-2-7B int8, group 64: dim 4096, hidden 11008, vocab 32000
   const Shape shapes[] = {
@@ -86,7 +103,14 @@ int main() {
     const size_t slab = (size_t)sh.rows * sh.rowbytes, sslab = slab / 64 * 4;
     char* w; float* sc;
     CK(hipMalloc(&w, slab * NL)); CK(hipMalloc(&sc, sslab * NL));
-    CK(hipMemset(w, 1, slab * NL)); CK(hipMemset(sc, 0, sslab * NL)); CK(hipDeviceSynchronize());
+    CK(hipMemset(w, 1, slab * NL)); CK(hipMemset(sc, 0, sslab * NL));
+    if (random_fill) {
+      hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (unsigned*)w, slab * NL / 4, 12345u);
+      hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (unsigned*)sc, sslab * NL / 4, 777u);
+      // scales: keep them finite floats: exponent 0x3B (2^-8), random mantissa
+      hipLaunchKernelGGL(k_fix_scales, dim3(4096), dim3(256), 0, 0, (unsigned*)sc, sslab * NL / 4);
+    }
+    CK(hipDeviceSynchronize());
     const int pairs = sh.rows / 2;
     const double bytes = (double)slab + (double)sslab + sh.extra_bytes;
     float best = 1e9f; char bestcfg[96] = "";
