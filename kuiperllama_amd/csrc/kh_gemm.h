@@ -2,7 +2,7 @@
 //
 // The reference feeds the prompt one token per forward pass (demo/main.cpp:20-22): every prompt
 // token streams all weights.  kh_prefill.h already shares one weight pass between 8 (fp32) / 4
-// (int8) tokens on the VALU; here up to KH_PG_TMAX = 128 prompt tokens share ONE pass and the
+// (int8) tokens on the VALU; here up to KH_PG_TMAX = 512 prompt tokens share ONE pass and the
 // contraction runs on MFMA:  C[rows, T] = W[rows, K] . Xn[T, K]^T  with
 //     v_mfma_f32_16x16x4_f32   (f32 in, f32 accumulate: bit-for-bit a k-ordered fmaf chain,
 //                               MI355X guide §3 — exact fp32, no reduced-precision path)
@@ -42,7 +42,14 @@
 #pragma once
 #include "kh_fused.h"
 
-#define KH_PG_TMAX 128           // prompt tokens per weight pass (8 MFMA token tiles)
+// Prompt tokens per weight pass.  128 tokens (8 MFMA token tiles) already put every GEMM above the
+// ridge; the reason to go further is the SMALL-M GEMMs (wo, w2, QKV): with 2048 rows x 128 tokens a
+// chip-filling launch is left with (1,4) / (2,2) register tiles, 512 tokens give them the (2,8)
+// tile of the SwiGLU GEMM in 256 workgroups (pg_shape).  The tiled slabs of a chunk use a token
+// stride `tcap` = its token count rounded up to KH_PG_TSTEP, so a 128-token chunk has exactly the
+// layout it always had.
+#define KH_PG_TMAX 512
+#define KH_PG_TSTEP 128
 // Workgroup width: <= 8 waves.  The fp32 shapes use 4 (ONE wave per SIMD, see pg_shape); int8 up to 8
 // (its dequant VALU work wants a partner wave on the SIMD to keep the matrix pipe busy).
 #define KH_PG_WG_MAX_F32 512
@@ -52,21 +59,23 @@
 enum { KH_PG_QKV = 0, KH_PG_RESID = 1, KH_PG_SWIGLU = 2 };
 
 // position (in floats) of activation element (token t, column k) in a tiled slab
-__host__ __device__ __forceinline__ size_t pg_tiled_index(bool quant, int k, int t) {
-  if (!quant) return ((size_t)(k >> 4) * KH_PG_TMAX + t) * 16 + (k & 15);
+__host__ __device__ __forceinline__ size_t pg_tiled_index(bool quant, int k, int t, int tcap) {
+  if (!quant) return ((size_t)(k >> 4) * tcap + t) * 16 + (k & 15);
   const int b = k >> 6, r = k & 63, h = r >> 4, q = (r >> 2) & 3, e = r & 3;
-  return ((((size_t)b * 4 + q) * KH_PG_TMAX + t) * 4 + h) * 4 + e;
+  return ((((size_t)b * 4 + q) * tcap + t) * 4 + h) * 4 + e;
 }
+static inline int pg_tcap(int T) { return (T + KH_PG_TSTEP - 1) / KH_PG_TSTEP * KH_PG_TSTEP; }
 
 struct KhPgGemmArgs {
   KhLin w[3];        // QKV: wq, wk, wv ; RESID: w[0] ; SWIGLU: w1, w3
-  const float* B;    // activation slab of KH_PG_TMAX token rows (rows >= T hold finite garbage)
+  const float* B;    // activation slab of tcap token rows (rows >= T hold finite garbage)
   float* out;        // QKV: Q [T][ldo] ; RESID: X [T][ldo] (+=) ; SWIGLU: H (tiled slab)
   float* kc;         // QKV: K cache rows of this layer, row (pos0 + t) * kv_dim
   float* vc;
   int rows0, rows1;  // QKV: rows of wq, rows of wk (= rows of wv); else rows0 = rows
   int ldo, K, T, pos0, gshift;
   int b_tiled;       // B is a tiled slab (else row-major [T][K])
+  int tcap;          // token stride of the tiled slabs (B when b_tiled, the SwiGLU output): pg_tcap(T)
   // QKV only: RoPE fused into the epilogue (0 = off: k_pg_rope runs afterwards).  KH_PG_ROPE_PAIRS:
   // the pair (2i, 2i+1) sits in one lane's float4 (interleaved mode, cpu/rope_kernel.cpp:98-121).
   // KH_PG_ROPE_TILES: half mode (rope_kernel.cpp:18-42) pairs row j with j + hs/2 - a wave's R = 2
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
 #pragma unroll
     for (int r = 0; r < R; ++r) wrow[r] = (const float*)W.w + (size_t)(wr0 + rstep * r + i) * K + 4 * h;
     if (a.b_tiled) {
-      B = PgBAddr{a.B + (size_t)(tok0 + i) * 16 + 4 * h, 256, (size_t)KH_PG_TMAX * 16, 0};
+      B = PgBAddr{a.B + (size_t)(tok0 + i) * 16 + 4 * h, 256, (size_t)a.tcap * 16, 0};
     } else {
       B = PgBAddr{a.B + (size_t)(tok0 + i) * K + 4 * h, (size_t)16 * K, 16, 0};
     }
@@ -343,8 +352,8 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
       srow[r] = W.scales + (size_t)(wr0 + rstep * r + i) * nb;
     }
     if (a.b_tiled) {
-      B = PgBAddr{a.B + (size_t)(tok0 + i) * 16 + 4 * h, 256, (size_t)4 * KH_PG_TMAX * 16,
-                  (size_t)KH_PG_TMAX * 16};
+      B = PgBAddr{a.B + (size_t)(tok0 + i) * 16 + 4 * h, 256, (size_t)4 * a.tcap * 16,
+                  (size_t)a.tcap * 16};
     } else {
       B = PgBAddr{a.B + (size_t)(tok0 + i) * K + 16 * h, (size_t)16 * K, 64, 4};
     }
@@ -455,11 +464,13 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
         o.y = swiglu1(v0.y, v1.y);
         o.z = swiglu1(v0.z, v1.z);
         o.w = swiglu1(v0.w, v1.w);
-        *(f32x4*)(a.out + pg_tiled_index(QUANT, orow, tok)) = o;  // H feeds the w2 GEMM: tiled slab
+        *(f32x4*)(a.out + pg_tiled_index(QUANT, orow, tok, a.tcap)) = o;  // H feeds the w2 GEMM: tiled slab
       }
     }
   }
 }
+// dynamic-LDS request that admits ONE workgroup per CU (more than half of the 160 KiB)
+#define KH_PG_SOLO_LDS ((size_t)81 * 1024)
 static inline size_t pg_lds_bytes(int waves, int nt) {
   return waves <= 1 ? 0 : (size_t)waves * nt * 64 * sizeof(f32x4);
 }
@@ -470,7 +481,8 @@ static inline size_t pg_lds_bytes(int waves, int nt) {
 template <bool QUANT>
 __global__ __launch_bounds__(KH_WG) void k_pg_rmsnorm(const float* __restrict__ X,
                                                       const float* __restrict__ w,
-                                                      float* __restrict__ Xn, int dim, float eps) {
+                                                      float* __restrict__ Xn, int dim, float eps,
+                                                      int tcap) {
   __shared__ float red[KH_WAVES_MAX];
   const int t = blockIdx.x;
   const f32x4* x4 = (const f32x4*)(X + (size_t)t * dim);
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(KH_WG) void k_pg_rmsnorm(const float* __restrict__ 
     o.y = g.y * (rs * v.y);
     o.z = g.z * (rs * v.z);
     o.w = g.w * (rs * v.w);
-    *(f32x4*)(Xn + pg_tiled_index(QUANT, 4 * k, t)) = o;
+    *(f32x4*)(Xn + pg_tiled_index(QUANT, 4 * k, t, tcap)) = o;
   }
 }
 

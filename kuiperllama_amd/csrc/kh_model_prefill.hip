@@ -263,14 +263,25 @@ int ensure_pg_buffers(kh_model* m) {
 //     (profiles/r2_gemm_shape_sweep_7b.txt: (w1,w3) 2 -> 4 waves per workgroup 30.4 -> 23.3 ms per
 //     prefill), up to what the register file admits;
 //   * bigger register tiles need fewer operand bytes per MFMA (small factor), more token slices
-//     re-read the weights from L2 (small factor), padding tokens are wasted MFMAs.
+//     re-read the weights from L2 (small factor), padding tokens are wasted MFMAs;
+//   * fp32 passes of more than 128 tokens launch several times 256 workgroups, which would sit two
+//     or more to a CU - two or more MFMA-bound waves per SIMD.  `solo` keeps ONE workgroup per CU at
+//     a time (a dynamic-LDS request above half the CU's 160 KiB; the workgroups of a CU then run back
+//     to back at the one-wave-per-SIMD rate) and is priced as such: Llama-3.2-1B, 512-token pass,
+//     56.4 k prompt tok/s with it, 38.0 k without (profiles/r3_prefill_wide.txt).  Passes of <= 128
+//     tokens use it for the MFMA-bound (2,8) tile only (Llama-2-7B fp32: 344 / 384 workgroups); their
+//     small latency-bound tiles gain from a partner wave, and whole rounds of 256 cost more than
+//     they save (Qwen2.5, (1,4) tile in 608 workgroups: 45.9 k shared, 41.8 k solo).
 struct PgShape {
   int R, NT, ks, slices;
+  bool solo;
 };
+static const bool pg_solo_env = [] { const char* e = getenv("KH_PG_SOLO"); return !(e && e[0] == '0'); }();
 PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min_blocks, bool quant) {
   const int nt_all = (T + 15) / 16;
+  const bool wide = nt_all > 8;  // a pass of more than 128 tokens
   static const int cand[4][3] = {{2, 8, 2}, {2, 4, 3}, {2, 2, 4}, {1, 4, 4}};  // R, NT, waves/SIMD that fit
-  PgShape best{1, 4, 1, (nt_all + 3) / 4};
+  PgShape best{1, 4, 1, (nt_all + 3) / 4, false};
   double best_cost = -1.0;
   for (const auto& c : cand) {
     const int R = c[0], NT = c[1], occ = c[2];
@@ -281,8 +292,12 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
     const long wgs = (long)(rows_total / (16 * R)) * slices;
     for (int ks = 1; ks * nm * 64 <= KH_PG_WG_MAX(quant); ks *= 2) {
       if (ks > 1 && kblocks / ks < min_blocks) break;  // keep a useful K range per wave
-      const long cu_waves = ((wgs + 255) / 256) * (long)(nm * ks);  // on the busiest CU
-      long wps = (cu_waves + 3) / 4;                                // waves per SIMD there
+      // waves per SIMD on the busiest CU.  A workgroup counts as one wave on EACH SIMD it touches:
+      // two 2-wave workgroups on a CU were measured on the same two SIMDs (Llama-3.2-1B, 256 tokens:
+      // the (2,8) SwiGLU tile with 2-wave workgroups 255 us against 2 x 83 us for two 128-token
+      // launches of 4-wave workgroups)
+      const long cu_wgs = (wgs + 255) / 256;
+      long wps = cu_wgs * ((nm * ks + 3) / 4);
       const long rounds = (wps + occ - 1) / occ;                    // beyond the register file: queued
       if (wps > occ) wps = occ;
       const double pen = quant ? (wps <= 1 ? 1.0 : (wps == 2 ? 0.72 : 0.62))
@@ -293,9 +308,18 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
       // every token slice re-reads the weights from L2 - and, int8, dequantises them again
       cost *= 1.0 + (quant ? 0.15 : 0.05) * (double)(slices - 1);
       cost *= (double)(slices * NT) / (double)nt_all;
+      bool solo = false;
+      if (!quant && (wide || R * NT >= 16) && pg_solo_env && wgs > 256) {
+        const long wg_wps = (nm * ks + 3) / 4;
+        const double c1 = per_wave * (double)(((wgs + 255) / 256) * wg_wps) * (wg_wps <= 1 ? 1.0 : (wg_wps == 2 ? 1.6 : 1.8));
+        if (c1 < per_wave * (double)(wps * rounds) * pen) {
+          cost *= c1 / (per_wave * (double)(wps * rounds) * pen);
+          solo = true;
+        }
+      }
       if (best_cost < 0 || cost < best_cost) {
         best_cost = cost;
-        best = PgShape{R, NT, ks, slices};
+        best = PgShape{R, NT, ks, slices, solo};
       }
     }
   }
@@ -303,7 +327,8 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
 }
 template <bool Q, int EPI>
 bool pg_launch_cfg(const PgShape& sh, int tiles, int wg, hipStream_t s, const KhPgGemmArgs& a) {
-  const size_t lds = pg_lds_bytes(wg / 64, sh.NT);
+  size_t lds = pg_lds_bytes(wg / 64, sh.NT);
+  if (sh.solo && lds < KH_PG_SOLO_LDS) lds = KH_PG_SOLO_LDS;  // one workgroup per CU at a time
   auto go = [&](auto kern) {
     if (lds > 48 * 1024) {
       // the >48 KiB dynamic-LDS opt-in is per (device, kernel): set once, not on every launch of
@@ -343,14 +368,18 @@ bool pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
       int R = 0, NT = 0, ks = 0;
       if (sscanf(ov, "%d,%d,%d", &R, &NT, &ks) == 3 && ((R == 2 && (NT == 2 || NT == 4 || NT == 8) && r2_ok) || (R == 1 && NT == 4)) &&
           (ks == 1 || ks == 2 || ks == 4 || ks == 8) && ks * nm * 64 <= KH_PG_WG_MAX(q))
-        sh = PgShape{R, NT, ks, ((a.T + 15) / 16 + NT - 1) / NT};
+      {
+        const int slices = ((a.T + 15) / 16 + NT - 1) / NT;
+        sh = PgShape{R, NT, ks, slices,
+                     !q && (a.T > 128 || R * NT >= 16) && pg_solo_env && (long)(rows_total / (16 * R)) * slices > 256};
+      }
     }
   }
   static const bool debug = getenv("KH_PG_DEBUG") != nullptr;
   if (debug)
-    fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d (%d wgs x %d waves)\n", EPI,
+    fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d (%d wgs x %d waves%s)\n", EPI,
             rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, rows_total / (16 * sh.R) * sh.slices,
-            nm * sh.ks);
+            nm * sh.ks, sh.solo ? ", solo" : "");
   if (EPI == KH_PG_QKV && a.rope == KH_PG_ROPE_TILES && (sh.R != 2 || sh.NT > 4))
     a.rope = KH_PG_ROPE_OFF;  // no partner tile in the wave / no registers to hold it: k_pg_rope follows
   const int tiles = rows_total / (16 * sh.R);
@@ -363,10 +392,11 @@ bool pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
 void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0) {
   const kh_config& c = m->cfg;
   const bool q = c.is_quant;
+  const int tcap = pg_tcap(T);  // token stride of this chunk's tiled slabs
   (void)kh_embedding_f32_host(toks, T, m->tok_emb, m->pg_x, c.dim, c.vocab_size, (void*)m->stream);
   auto rmsnorm = [&](const float* w) {
-    if (q) hipLaunchKernelGGL(k_pg_rmsnorm<true>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps);
-    else hipLaunchKernelGGL(k_pg_rmsnorm<false>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps);
+    if (q) hipLaunchKernelGGL(k_pg_rmsnorm<true>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps, tcap);
+    else hipLaunchKernelGGL(k_pg_rmsnorm<false>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps, tcap);
   };
   // attention of the slice: MFMA kernel (kh_pattn.h) unless KH_PG_ATTN=0 or an odd head size
   static const bool attn_env = [] { const char* e = getenv("KH_PG_ATTN"); return !(e && e[0] == '0'); }();
@@ -381,7 +411,7 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
     {
       KhPgGemmArgs a{};
       a.w[0] = W.wq; a.w[1] = W.wk; a.w[2] = W.wv;
-      a.B = m->pg_xn; a.b_tiled = 1; a.out = m->pg_q; a.kc = kc; a.vc = vc;
+      a.B = m->pg_xn; a.b_tiled = 1; a.tcap = tcap; a.out = m->pg_q; a.kc = kc; a.vc = vc;
       a.rows0 = c.dim; a.rows1 = c.kv_dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.pos0 = pos0;
       a.gshift = m->gshift;
       // RoPE in the epilogue: interleaved pairs sit in one lane's float4; half-mode partners need the
@@ -399,7 +429,7 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       KhPgAttnArgs a{};
       a.q = m->pg_q; a.kc = kc; a.vc = vc; a.out = m->pg_att;
       a.dim = c.dim; a.kv_dim = c.kv_dim; a.kv_heads = c.kv_head_num; a.kv_mul = c.kv_mul;
-      a.T = T; a.pos0 = pos0; a.layout = q ? KH_PA_TILED_Q8 : KH_PA_TILED_F32;
+      a.T = T; a.pos0 = pos0; a.layout = q ? KH_PA_TILED_Q8 : KH_PA_TILED_F32; a.tcap = tcap;
       launch_pg_attn(a, c.head_size, m->stream);
     } else {
       KhAttnArgs a = fill_attn(m, l);
@@ -417,7 +447,7 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
     {
       KhPgGemmArgs a{};
       a.w[0] = W.wo;
-      a.B = m->pg_att; a.b_tiled = mfma_attn ? 1 : 0; a.out = m->pg_x;  // decode kernel: row-major rows
+      a.B = m->pg_att; a.b_tiled = mfma_attn ? 1 : 0; a.tcap = tcap; a.out = m->pg_x;  // decode kernel: row-major rows
       a.rows0 = c.dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
       pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
     }
@@ -425,14 +455,14 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
     {
       KhPgGemmArgs a{};
       a.w[0] = W.w1; a.w[1] = W.w3;
-      a.B = m->pg_xn; a.b_tiled = 1; a.out = m->pg_h;
+      a.B = m->pg_xn; a.b_tiled = 1; a.tcap = tcap; a.out = m->pg_h;
       a.rows0 = c.hidden_dim; a.ldo = c.hidden_dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
       pg_launch<KH_PG_SWIGLU>(m, c.hidden_dim, c.hidden_dim % 32 == 0, a);
     }
     {
       KhPgGemmArgs a{};
       a.w[0] = W.w2;
-      a.B = m->pg_h; a.b_tiled = 1; a.out = m->pg_x;
+      a.B = m->pg_h; a.b_tiled = 1; a.tcap = tcap; a.out = m->pg_x;
       a.rows0 = c.dim; a.ldo = c.dim; a.K = c.hidden_dim; a.T = T; a.gshift = m->gshift;
       pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
     }
@@ -451,8 +481,14 @@ extern "C" int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32
   int rc;
   if ((rc = ensure_pg_buffers(m)) != KH_OK) return rc;
   m->pg_launch_failed = false;
-  for (int t0 = 0; t0 < n; t0 += KH_PG_TMAX)
-    launch_prefill_gemm_chunk(m, h_tokens + t0, n - t0 < KH_PG_TMAX ? n - t0 : KH_PG_TMAX, pos0 + t0);
+  // tuning / test hook: KH_PG_CHUNK=<tokens per weight pass> (16 .. KH_PG_TMAX), read per call
+  int chunk = KH_PG_TMAX;
+  if (const char* e = getenv("KH_PG_CHUNK")) {
+    const int v = atoi(e);
+    chunk = v < 16 ? 16 : (v > KH_PG_TMAX ? KH_PG_TMAX : v);
+  }
+  for (int t0 = 0; t0 < n; t0 += chunk)
+    launch_prefill_gemm_chunk(m, h_tokens + t0, n - t0 < chunk ? n - t0 : chunk, pos0 + t0);
   if (m->pg_launch_failed) return KH_ERR_UNSUPPORTED;  // a GEMM shape's LDS opt-in was refused
   return kh_launch_status();
 }

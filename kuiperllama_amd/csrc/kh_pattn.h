@@ -33,9 +33,9 @@ struct KhPgAttnArgs {
   const float* q;   // [T][dim] row-major, RoPE applied
   const float* kc;  // this layer's K cache rows [cache_len][kv_dim]; rows pos0 .. pos0+T-1 just written
   const float* vc;
-  float* out;       // layout 0 / 1: tiled slab [dim x KH_PG_TMAX] of an fp32 / int8 model
-                    // (pg_tiled_index, T <= KH_PG_TMAX); layout 2: row-major [T][dim]
-  int dim, kv_dim, kv_heads, kv_mul, T, pos0, layout;
+  float* out;       // layout 0 / 1: tiled slab [dim x tcap] of an fp32 / int8 model
+                    // (pg_tiled_index, T <= tcap); layout 2: row-major [T][dim]
+  int dim, kv_dim, kv_heads, kv_mul, T, pos0, layout, tcap;
 };
 enum { KH_PA_TILED_F32 = 0, KH_PA_TILED_Q8 = 1, KH_PA_ROWS = 2 };
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void k_pg_attn(const KhPgAttnArgs a) {
       r.x /= L; r.y /= L; r.z /= L; r.w /= L;
       const int k = h * HS + 4 * grp, t = t0 + tok;
       const size_t at = a.layout == KH_PA_ROWS ? (size_t)t * a.dim + k
-                                               : pg_tiled_index(a.layout == KH_PA_TILED_Q8, k, t);
+                                               : pg_tiled_index(a.layout == KH_PA_TILED_Q8, k, t, a.tcap);
       *(f32x4*)(a.out + at) = r;
     }
   }

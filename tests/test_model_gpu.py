@@ -609,6 +609,80 @@ def test_gemm_prefill_matches_oracle(gpu, oracle, name):
         m.close()
 
 
+@pytest.mark.parametrize("name", ["gqa-half", "qwen-bias", "int8", "gqa-half-hs128"])
+def test_gemm_prefill_wide_chunks_match_oracle(gpu, oracle, name, monkeypatch):
+    """Weight passes of more than 128 prompt tokens (KH_PG_TMAX = 512: several 16*NT-token slices per
+    GEMM launch, slab token strides 256 / 384 / 512, one-workgroup-per-CU launches): 300 tokens (one
+    partial chunk), 512 (one full chunk), 600 (512, then 88 at start position 512) and 200 + 330
+    (second call at a non-zero start position, one 330-token chunk) against the CPU oracle fed the same
+    tokens one by one - cache rows of every layer, the next step's logits and token; then the same
+    600 tokens in 128-token passes (KH_PG_CHUNK=128), which must agree to the same tolerance."""
+    import dataclasses
+    from kuiperllama_amd.model import KuiperModel
+    spec = dataclasses.replace(_PF_SPECS[name], seq_len=1024)
+    img_d, img_h = _synth(spec, 78, gpu)
+    rng = np.random.default_rng(10)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, 601)]
+    kv_atol = KV_ATOL_GEMM * (4 if spec.quant else 1)
+    om = oracle.OracleModel.from_spec(img_h, spec)
+    want_logits = {}
+    for i, t in enumerate(toks):
+        lo = om.forward(int(t), i)
+        if i in (300, 512, 530, 600):
+            want_logits[i] = lo.copy()
+    ko, vo = om.kv_cache()
+    for first, extra, chunk in ((300, 0, None), (512, 0, None), (600, 0, None), (200, 330, None), (600, 0, "128")):
+        if chunk:
+            monkeypatch.setenv("KH_PG_CHUNK", chunk)
+        m = KuiperModel.from_device_image(img_d, spec)
+        m.prefill_gemm(toks[:first], 0)
+        if extra:
+            m.prefill_gemm(toks[first:first + extra], first)
+        n = first + extra
+        for layer in range(spec.n_layers):
+            kg, vg = m.read_kv(layer, 0, n)
+            np.testing.assert_allclose(kg, ko[layer, :n], rtol=0, atol=kv_atol, err_msg=f"{name} n={n} K l{layer}")
+            np.testing.assert_allclose(vg, vo[layer, :n], rtol=0, atol=kv_atol, err_msg=f"{name} n={n} V l{layer}")
+        nxt = m.predict(toks[n], n, exec="fused")
+        np.testing.assert_allclose(m.logits(), want_logits[n], rtol=0, atol=_atol(spec))
+        assert nxt == int(np.argmax(want_logits[n]))
+        m.close()
+        monkeypatch.delenv("KH_PG_CHUNK", raising=False)
+
+
+@pytest.mark.parametrize("preset", ["llama3.2-1b", "llama2-7b-int8"])
+def test_gemm_prefill_full_size_wide_chunk(gpu, preset):
+    """Full BASELINE shapes, 512 prompt tokens in ONE weight pass (the small-M GEMMs on the (2,8) tile,
+    four token slices per launch) against the bit-exact B-token path (itself identical to token-by-token
+    passes, test_prefill_full_size_bit_identical): K/V rows of the first and the last layer, the
+    following step's logits and token.  (512 oracle passes over these images would take many minutes;
+    the 128-token pass is held to the oracle in test_gemm_prefill_full_size.)"""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.PRESETS[preset]
+    img_d = binfmt.synth_image(spec, seed=4321, device=gpu)  # (no host copy: no oracle leg here)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(2)
+    n = 512
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, n + 1)]
+    layers = (0, spec.n_layers - 1)
+    out = []
+    for mode in ("gemm", "gemv"):
+        m = KuiperModel.from_device_image(img_d, spec, max_seq_len=640)
+        (m.prefill_gemm if mode == "gemm" else m.prefill)(toks[:n], 0)
+        kv = [m.read_kv(l, 0, n) for l in layers]
+        nxt = m.predict(toks[n], n, exec="fused")
+        out.append((kv, nxt, m.logits().copy()))
+        m.close()
+    (ka, na, la), (kb, nb, lb) = out
+    for li, ((k1, v1), (k2, v2)) in enumerate(zip(ka, kb)):
+        e = max(np.abs(k1 - k2).max(), np.abs(v1 - v2).max())
+        print(f"layer {layers[li]}: |gemm(512) - b-token path| {e:.2e}")
+        bound = (2e-5 if li == 0 else 2e-4) if spec.quant else (5e-6 if li == 0 else 5e-5)
+        assert e <= bound, (layers[li], e)
+    np.testing.assert_allclose(la, lb, rtol=0, atol=_atol(spec) * 2)
+    assert na == nb
+
+
 @pytest.mark.parametrize("name", ["gqa-half", "int8"])
 def test_generate_long_prompt_takes_gemm_prefill(gpu, oracle, name, monkeypatch):
     """Prompts with >= 16 fed-only tokens go through the GEMM prefill inside generate(); the words

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prompt-phase time of the MFMA GEMM prefill alone (kh_model_time_prefill, HIP events on the model
-stream): ms and prompt tok/s for a 128-token slice at position 0, best of 5 (run on the GPU box;
+stream): ms and prompt tok/s for 128- ... 1024-token prompts at position 0, best of 5 / 3 (GPU box;
 KH_LIB selects an experiment build).   usage: tools/prefill_time.py [label] workload..."""
 import json
 import os
@@ -25,10 +25,12 @@ for name in sys.argv[2:] or ["llama3.2-1b"]:
     m.time_prefill(toks, 0, "gemm")
     ms = min(m.time_prefill(toks, 0, "gemm") for _ in range(5))
     row = {"label": label, "workload": name, "ms_128": round(ms, 4), "prompt_tok_s": round(128 / ms * 1e3)}
-    if spec.seq_len >= 1024:
-        lp = [int(t) for t in rng.integers(0, spec.vocab_size, 1024)]
-        ms2 = min(m.time_prefill(lp, 0, "gemm") for _ in range(2))
-        row["prompt_tok_s_1024"] = round(1024 / ms2 * 1e3)
+    for n in (256, 384, 512, 640, 1024):  # longer prompts: weight passes of up to KH_PG_TMAX tokens (KH_PG_CHUNK to A/B)
+        if spec.seq_len >= n:
+            lp = [int(t) for t in rng.integers(0, spec.vocab_size, n)]
+            m.time_prefill(lp, 0, "gemm")
+            ms2 = min(m.time_prefill(lp, 0, "gemm") for _ in range(3))
+            row[f"prompt_tok_s_{n}"] = round(n / ms2 * 1e3)
     print(json.dumps(row), flush=True)
     m.close()
     del img, m
