@@ -243,8 +243,9 @@ int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int32_t n_prom
  * geometries outside the mirrored kernels (head_size <= 32, dim > 4096). */
 int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
 
-/* The same contract with the contractions as fp32-MFMA GEMMs (csrc/kh_gemm.h): up to 128 prompt
- * tokens share one pass over the weights (v_mfma_f32_16x16x4_f32, exact fp32 arithmetic, tokens on
+/* The same contract with the contractions as fp32-MFMA GEMMs (csrc/kh_gemm.h): up to 512 prompt
+ * tokens share one pass over the weights (a longer prompt is cut into 512-token passes plus a
+ * remainder; env KH_PG_CHUNK = 16..512 sets another pass size) (v_mfma_f32_16x16x4_f32, exact fp32 arithmetic, tokens on
  * the MFMA N dimension; int8 weights dequantised per element in registers).  The K/V rows agree
  * with the token-by-token path to fp32 round-off (different summation order), not bit for bit.
  * kh_model_generate* use it for prompts with >= 16 fed-only tokens - so for such prompts the greedy
