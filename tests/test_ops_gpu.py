@@ -320,14 +320,19 @@ def test_mha_long_context_multi_chunk(gpu, oracle):
         np.testing.assert_allclose(host(out2), oo, rtol=0, atol=3e-5)
 
 
+@pytest.mark.parametrize("qt", ["auto", "2", "4"])
 @pytest.mark.parametrize("heads,kv_heads,hs", [(8, 2, 64), (4, 4, 128), (6, 6, 48), (14, 2, 64)])
-def test_mha_prefill_mfma_vs_oracle(gpu, oracle, heads, kv_heads, hs):
+def test_mha_prefill_mfma_vs_oracle(gpu, oracle, heads, kv_heads, hs, qt, monkeypatch):
     """kh_mha_prefill_f32 (kh_pattn.h: q.K^T and P.V on v_mfma_f32_16x16x4_f32, online softmax) against
     the oracle's one-query-at-a-time MHA (cpu/mha_kernel.cpp:5-61) for every token of the slice:
     slices that start at 0, at a position that is not a multiple of the 16-timestep tile, deep in
     the cache; token counts with partial tiles; a spiked key that forces the running-max rescale
-    in a LATER tile; GQA / MHA head mappings and the three head sizes."""
+    in a LATER tile; GQA / MHA head mappings and the three head sizes.  qt: 16-token query tiles per
+    workgroup (auto = what the launch picks for these small head counts, i.e. 1; 2 / 4 forced through
+    KH_PG_ATTN_QT - head size 128 caps at 2), checked at tokens on both sides of every tile seam."""
     from kuiperllama_amd import ops
+    if qt != "auto":
+        monkeypatch.setenv("KH_PG_ATTN_QT", qt)
     seq, layers = 1500, 2
     rng = np.random.default_rng(heads * 10 + hs)
     kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
@@ -336,13 +341,13 @@ def test_mha_prefill_mfma_vs_oracle(gpu, oracle, heads, kv_heads, hs):
     qs = rng.standard_normal((256, dim)).astype(np.float32)
     kc[1, 700, :hs] = 3.0 * qs[3, :hs]  # every head of kv group 0, token 3: a huge score at t = 700
     kcd, vcd = dev(kc, gpu), dev(vc, gpu)
-    for layer, pos0, n in ((0, 0, 1), (0, 0, 16), (0, 0, 37), (0, 0, 128), (1, 5, 100), (1, 690, 33),
-                           (1, 1244, 256), (0, 1499, 1)):
+    for layer, pos0, n in ((0, 0, 1), (0, 0, 16), (0, 0, 37), (0, 0, 128), (0, 0, 256), (1, 5, 100),
+                           (1, 690, 33), (1, 1244, 256), (0, 1499, 1)):
         q = np.ascontiguousarray(qs[:n])
         out = torch.full((n, dim), float("nan"), device=gpu)
         ops.mha_prefill(pos0, n, heads, layer, seq, kv_dim, kv_mul, hs, out, dev(q, gpu), kcd, vcd)
         got = host(out)
-        for t in sorted({0, 1, n // 2, n - 2, n - 1} & set(range(n))):
+        for t in sorted({0, 1, 15, 16, 17, 31, 32, 47, 48, 63, 64, n // 2, n - 2, n - 1} & set(range(n))):
             oo, _ = oracle.mha(pos0 + t, heads, layer, seq, kv_dim, kv_mul, hs, q[t], kc, vc,
                                acc=oracle.ACC_F64)
             np.testing.assert_allclose(got[t], oo, rtol=0, atol=3e-5,
