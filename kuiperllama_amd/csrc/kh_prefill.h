@@ -168,8 +168,8 @@ __device__ __forceinline__ void gemv_pairs_b(const Gemv<QUANT, U>& g, const f32x
     auto aux_next = aux;
     if (pn < total) {
       cur = PAIR(pn);
-      g.load(regs, cur, cb, ce, lane);
-      aux_next = PRE(pn);
+      aux_next = PRE(pn);  // ahead of the tile: the youngest loads at the latch are then weight loads
+      g.load(regs, cur, cb, ce, lane);  // (kh_gemv.h::gemv_pairs: a vmcnt(0) drain otherwise)
     }
     float s0[B], s1[B];
 #pragma unroll
