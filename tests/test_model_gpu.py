@@ -650,39 +650,6 @@ def test_gemm_prefill_wide_chunks_match_oracle(gpu, oracle, name, monkeypatch):
         monkeypatch.delenv("KH_PG_CHUNK", raising=False)
 
 
-@pytest.mark.parametrize("preset", ["llama3.2-1b", "llama2-7b-int8"])
-def test_gemm_prefill_full_size_wide_chunk(gpu, preset):
-    """Full BASELINE shapes, 512 prompt tokens in ONE weight pass (the small-M GEMMs on the (2,8) tile,
-    four token slices per launch) against the bit-exact B-token path (itself identical to token-by-token
-    passes, test_prefill_full_size_bit_identical): K/V rows of the first and the last layer, the
-    following step's logits and token.  (512 oracle passes over these images would take many minutes;
-    the 128-token pass is held to the oracle in test_gemm_prefill_full_size.)"""
-    from kuiperllama_amd.model import KuiperModel
-    spec = binfmt.PRESETS[preset]
-    img_d = binfmt.synth_image(spec, seed=4321, device=gpu)  # (no host copy: no oracle leg here)
-    torch.cuda.synchronize()
-    rng = np.random.default_rng(2)
-    n = 512
-    toks = [int(t) for t in rng.integers(0, spec.vocab_size, n + 1)]
-    layers = (0, spec.n_layers - 1)
-    out = []
-    for mode in ("gemm", "gemv"):
-        m = KuiperModel.from_device_image(img_d, spec, max_seq_len=640)
-        (m.prefill_gemm if mode == "gemm" else m.prefill)(toks[:n], 0)
-        kv = [m.read_kv(l, 0, n) for l in layers]
-        nxt = m.predict(toks[n], n, exec="fused")
-        out.append((kv, nxt, m.logits().copy()))
-        m.close()
-    (ka, na, la), (kb, nb, lb) = out
-    for li, ((k1, v1), (k2, v2)) in enumerate(zip(ka, kb)):
-        e = max(np.abs(k1 - k2).max(), np.abs(v1 - v2).max())
-        print(f"layer {layers[li]}: |gemm(512) - b-token path| {e:.2e}")
-        bound = (2e-5 if li == 0 else 2e-4) if spec.quant else (5e-6 if li == 0 else 5e-5)
-        assert e <= bound, (layers[li], e)
-    np.testing.assert_allclose(la, lb, rtol=0, atol=_atol(spec) * 2)
-    assert na == nb
-
-
 @pytest.mark.parametrize("name", ["gqa-half", "int8"])
 def test_generate_long_prompt_takes_gemm_prefill(gpu, oracle, name, monkeypatch):
     """Prompts with >= 16 fed-only tokens go through the GEMM prefill inside generate(); the words
@@ -713,23 +680,25 @@ def test_generate_long_prompt_takes_gemm_prefill(gpu, oracle, name, monkeypatch)
     m.close()
 
 
+@pytest.mark.parametrize("n", [128, 512])
 @pytest.mark.parametrize("preset", ["llama3.2-1b", "llama2-7b-int8"])
-def test_gemm_prefill_full_size(gpu, oracle, preset):
-    """Full BASELINE shapes, 128 prompt tokens in one weight pass.  Llama-3.2-1B: K/V rows of the
+def test_gemm_prefill_full_size(gpu, oracle, preset, n):
+    """Full BASELINE shapes, 128 or 512 prompt tokens in ONE weight pass (512: the small-M GEMMs on the
+    (2,8) tile, four token slices per launch, one workgroup per CU).  Llama-3.2-1B: K/V rows of the
     first and last layer against the oracle - 5e-6 at layer 0; at layer 15 every fp32 path has
     accumulated 16 layers of round-off, so the bound there is stated against the fp64-accumulated
     gold: the GEMM path (k-ordered fp32 fmaf chains of up to 2048 terms) may be at most 3x as far
     from it as the fp32 oracle (16-way blocked sums) itself is, and within 5e-5 absolute.  7B int8:
-    the rows of the first 16 tokens in layers 0 and 31 against the ORACLE, then all 128 tokens
+    the rows of the first 16 tokens in layers 0 and 31 against the ORACLE, then all n tokens
     against the bit-exact B-token path.
     Both: following logits within tolerance and the same next token."""
     from kuiperllama_amd.model import KuiperModel
     spec = binfmt.PRESETS[preset]
     img_d, img_h = _synth(spec, 4321, gpu)
     rng = np.random.default_rng(1)
-    toks = [int(t) for t in rng.integers(0, spec.vocab_size, 129)]
-    n = 128
-    a = KuiperModel.from_device_image(img_d, spec, max_seq_len=256)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, n + 1)]
+    cap = n + 128
+    a = KuiperModel.from_device_image(img_d, spec, max_seq_len=cap)
     a.prefill_gemm(toks[:n], 0)
     layers = (0, spec.n_layers - 1)
     ka = [a.read_kv(l, 0, n) for l in layers]
@@ -737,11 +706,11 @@ def test_gemm_prefill_full_size(gpu, oracle, preset):
     la = a.logits().copy()
     a.close()
     if not spec.quant:
-        om = _oracle_kv_after(oracle, img_h, spec, toks[:n], cache_len=256)
+        om = _oracle_kv_after(oracle, img_h, spec, toks[:n], cache_len=cap)
         ko, vo = om.kv_cache()
         ref = [(ko[l, :n].copy(), vo[l, :n].copy()) for l in layers]
         lo = om.forward(toks[n], n)
-        og = oracle.OracleModel.from_spec(img_h, spec, cache_len=256)
+        og = oracle.OracleModel.from_spec(img_h, spec, cache_len=cap)
         for i, t in enumerate(toks[:n]):
             og.forward(int(t), i, oracle.ACC_F64)
         kg, vg = og.kv_cache()
@@ -759,16 +728,16 @@ def test_gemm_prefill_full_size(gpu, oracle, preset):
         # (i) against the ORACLE: K/V rows of the first 16 prompt tokens (causal: they depend on
         # those tokens only) in the first and the last layer - 16 CPU passes over the 7 GB image
         n_or = 16
-        om = _oracle_kv_after(oracle, img_h, spec, toks[:n_or], cache_len=256)
+        om = _oracle_kv_after(oracle, img_h, spec, toks[:n_or], cache_len=cap)
         ko, vo = om.kv_cache()
         for li, (l, (k1, v1)) in enumerate(zip(layers, ka)):
             e_or = max(np.abs(k1[:n_or] - ko[l, :n_or]).max(), np.abs(v1[:n_or] - vo[l, :n_or]).max())
             print(f"layer {l}: |gemm - oracle| over {n_or} tokens {e_or:.2e}")
             assert e_or <= (2e-5 if li == 0 else 2e-4), (l, e_or)
         del om, ko, vo
-        # (ii) all 128 tokens and the following step's logits against the bit-exact B-token path
-        # (a full 129-step oracle pass over this image would take minutes)
-        b = KuiperModel.from_device_image(img_d, spec, max_seq_len=256)
+        # (ii) all n tokens and the following step's logits against the bit-exact B-token path
+        # (a full oracle pass over this image would take minutes)
+        b = KuiperModel.from_device_image(img_d, spec, max_seq_len=cap)
         b.prefill(toks[:n], 0)
         ref = [b.read_kv(l, 0, n) for l in layers]
         b.predict(toks[n], n, exec="fused")
