@@ -50,6 +50,7 @@
 // layout it always had.
 #define KH_PG_TMAX 512
 #define KH_PG_TSTEP 128
+#define KH_PG_KZ_MAX 4         // K slices across workgroups of a residual GEMM (partial rows, see KhPgGemmArgs)
 // Workgroup width: <= 8 waves.  The fp32 shapes use 4 (ONE wave per SIMD, see pg_shape); int8 up to 8
 // (its dequant VALU work wants a partner wave on the SIMD to keep the matrix pipe busy).
 #define KH_PG_WG_MAX_F32 512
@@ -76,6 +77,10 @@ struct KhPgGemmArgs {
   int ldo, K, T, pos0, gshift;
   int b_tiled;       // B is a tiled slab (else row-major [T][K])
   int tcap;          // token stride of the tiled slabs (B when b_tiled, the SwiGLU output): pg_tcap(T)
+  // RESID only: K split ACROSS workgroups (gridDim.z = kz > 1).  Slice z stores its partial rows to
+  // part[z][tok][ldo] (plain stores, no read-modify-write); the RMSNorm kernel that follows adds the
+  // kz partials to X in fixed order (k_pg_rmsnorm) - no ticket, no fence, deterministic.
+  float* part;
   // QKV only: RoPE fused into the epilogue (0 = off: k_pg_rope runs afterwards).  KH_PG_ROPE_PAIRS:
   // the pair (2i, 2i+1) sits in one lane's float4 (interleaved mode, cpu/rope_kernel.cpp:98-121).
   // KH_PG_ROPE_TILES: half mode (rope_kernel.cpp:18-42) pairs row j with j + hs/2 - a wave's R = 2
@@ -319,8 +324,9 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
   PgBAddr B;
   if (!QUANT) {
     const int nb = K >> 4;
-    const int b0 = __builtin_amdgcn_readfirstlane((int)((long)kpart * nb / ks));
-    const int b1 = __builtin_amdgcn_readfirstlane((int)((long)(kpart + 1) * nb / ks));
+    const int z0 = (int)((long)blockIdx.z * nb / gridDim.z), z1 = (int)((long)(blockIdx.z + 1) * nb / gridDim.z);
+    const int b0 = __builtin_amdgcn_readfirstlane(z0 + (int)((long)kpart * (z1 - z0) / ks));
+    const int b1 = __builtin_amdgcn_readfirstlane(z0 + (int)((long)(kpart + 1) * (z1 - z0) / ks));
     const float* wrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wrow[r] = (const float*)W.w + (size_t)(wr0 + rstep * r + i) * K + 4 * h;
@@ -342,8 +348,9 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
     }
   } else {
     const int nb = K >> 6;
-    const int b0 = __builtin_amdgcn_readfirstlane((int)((long)kpart * nb / ks));
-    const int b1 = __builtin_amdgcn_readfirstlane((int)((long)(kpart + 1) * nb / ks));
+    const int z0 = (int)((long)blockIdx.z * nb / gridDim.z), z1 = (int)((long)(blockIdx.z + 1) * nb / gridDim.z);
+    const int b0 = __builtin_amdgcn_readfirstlane(z0 + (int)((long)kpart * (z1 - z0) / ks));
+    const int b1 = __builtin_amdgcn_readfirstlane(z0 + (int)((long)(kpart + 1) * (z1 - z0) / ks));
     const int8_t* wrow[R];
     const float* srow[R];
 #pragma unroll
@@ -454,10 +461,14 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
           *(f32x4*)(dst + rr) = v0;
         }
       } else if (EPI == KH_PG_RESID) {
-        f32x4* dst = (f32x4*)(a.out + (size_t)tok * a.ldo + orow);
-        f32x4 x = *dst;
-        x.x += v0.x; x.y += v0.y; x.z += v0.z; x.w += v0.w;  // residual add (llama3.cpp:686,719)
-        *dst = x;
+        if (gridDim.z > 1) {  // K slice of a cross-workgroup split: the following k_pg_rmsnorm adds it
+          *(f32x4*)(a.part + ((size_t)blockIdx.z * a.tcap + tok) * a.ldo + orow) = v0;
+        } else {
+          f32x4* dst = (f32x4*)(a.out + (size_t)tok * a.ldo + orow);
+          f32x4 x = *dst;
+          x.x += v0.x; x.y += v0.y; x.z += v0.z; x.w += v0.w;  // residual add (llama3.cpp:686,719)
+          *dst = x;
+        }
       } else {
         f32x4 o;
         o.x = swiglu1(v0.x, v1.x);
@@ -477,20 +488,29 @@ static inline size_t pg_lds_bytes(int waves, int nt) {
 
 // ---- the small per-token kernels between the GEMMs ---------------------------------------------
 // Xn[t] = w * (x[t] / sqrt(mean(x[t]^2) + eps))   (cpu/rmsnorm_kernel.cpp:24-32), one workgroup per
-// token; Xn is written as the tiled slab the QKV / FFN GEMMs read.
+// token; Xn is written as the tiled slab the QKV / FFN GEMMs read.  kz > 0: the residual GEMM in front
+// of it split K across workgroups - its kz partial rows part[z][t][dim] are added to X first, in fixed
+// order (the residual add of llama3.cpp:686,719, deferred).
 template <bool QUANT>
-__global__ __launch_bounds__(KH_WG) void k_pg_rmsnorm(const float* __restrict__ X,
+__global__ __launch_bounds__(KH_WG) void k_pg_rmsnorm(float* __restrict__ X,
                                                       const float* __restrict__ w,
                                                       float* __restrict__ Xn, int dim, float eps,
-                                                      int tcap) {
+                                                      int tcap, const float* __restrict__ part, int kz) {
   __shared__ float red[KH_WAVES_MAX];
   const int t = blockIdx.x;
-  const f32x4* x4 = (const f32x4*)(X + (size_t)t * dim);
+  f32x4* x4 = (f32x4*)(X + (size_t)t * dim);
   const f32x4* w4 = (const f32x4*)w;
   const int n4 = dim >> 2;
   float ss = 0.f;
   for (int k = threadIdx.x; k < n4; k += KH_WG) {
-    const f32x4 v = x4[k];
+    f32x4 v = x4[k];
+    if (kz > 0) {
+      for (int z = 0; z < kz; ++z) {
+        const f32x4 p = *(const f32x4*)(part + ((size_t)z * tcap + t) * dim + 4 * k);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      x4[k] = v;  // (re-read by this same thread below)
+    }
     ss = fma4(v, v, ss);
   }
   ss = block_sum(ss, red);

@@ -61,6 +61,7 @@ struct kh_model {
   size_t pf_ws_tok_bytes = 0;
   // GEMM prefill (kh_gemm.h): slabs of KH_PG_TMAX token rows
   float *pg_x = nullptr, *pg_xn = nullptr, *pg_q = nullptr, *pg_att = nullptr, *pg_h = nullptr;
+  float* pg_part = nullptr;     // partial rows of residual GEMMs that split K across workgroups
   void* pg_ws = nullptr;        // KH_PG_TMAX attention split workspaces
   size_t pg_ws_tok_bytes = 0;
   bool pf_ready = false, pg_ready = false;  // set when ALL prefill slabs exist (allocation can fail half-way)

@@ -354,7 +354,7 @@ extern "C" void kh_model_destroy(kh_model* m) {
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   for (void* q : {(void*)m->pf_x, (void*)m->pf_q, (void*)m->pf_att, (void*)m->pf_h, m->pf_ws,
-                  (void*)m->pg_x, (void*)m->pg_xn, (void*)m->pg_q, (void*)m->pg_att, (void*)m->pg_h,
+                  (void*)m->pg_x, (void*)m->pg_xn, (void*)m->pg_q, (void*)m->pg_att, (void*)m->pg_h, (void*)m->pg_part,
                   m->pg_ws})
     if (q) (void)hipFree(q);
   for (auto e : m->ev_chunk)

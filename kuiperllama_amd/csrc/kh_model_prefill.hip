@@ -185,6 +185,9 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
       else if (B == 8) pf_launch_qkv<false, 8>(m, a);
       else pf_launch_qkv<false, 4>(m, a);
     }
+    // the prompt phase leaves K/V rows and nothing else (no logits): the last layer's K/V rows are
+    // written, its attention, wo and FFN feed nothing
+    if (l == c.layer_num - 1) break;
     {
       KhAttnArgs a = fill_attn(m, l);
       a.q = m->pf_q;
@@ -223,7 +226,7 @@ int ensure_pg_buffers(kh_model* m) {
   if (m->pg_ready) return KH_OK;
   // a previous attempt may have failed half-way (out of memory): start from a clean slate so a
   // later call never launches GEMMs on null slabs
-  for (float** p : {&m->pg_x, &m->pg_xn, &m->pg_q, &m->pg_att, &m->pg_h}) {
+  for (float** p : {&m->pg_x, &m->pg_xn, &m->pg_q, &m->pg_att, &m->pg_h, &m->pg_part}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -243,6 +246,7 @@ int ensure_pg_buffers(kh_model* m) {
   if ((rc = zalloc(&m->pg_q, T * c.dim)) != KH_OK) return rc;
   if ((rc = zalloc(&m->pg_att, T * c.dim)) != KH_OK) return rc;
   if ((rc = zalloc(&m->pg_h, T * c.hidden_dim)) != KH_OK) return rc;
+  if ((rc = zalloc(&m->pg_part, (size_t)KH_PG_KZ_MAX * T * c.dim)) != KH_OK) return rc;  // K-slice partial rows
   m->pg_ws_tok_bytes = (attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride) + 255) & ~(size_t)255;
   if (m->pg_ws_tok_bytes) {
     KH_CHECK_HIP(hipMalloc(&m->pg_ws, m->pg_ws_tok_bytes * T));
@@ -272,16 +276,23 @@ int ensure_pg_buffers(kh_model* m) {
 //     tokens use it for the MFMA-bound (2,8) tile only (Llama-2-7B fp32: 344 / 384 workgroups); their
 //     small latency-bound tiles gain from a partner wave, and whole rounds of 256 cost more than
 //     they save (Qwen2.5, (1,4) tile in 608 workgroups: 45.9 k shared, 41.8 k solo).
+//   * the residual GEMMs (wo, w2) may split K across `kz` workgroups as well (blockIdx.z): with 2048
+//     rows x 128 tokens there are only 64 (2,8) tiles, so a chip-filling launch either takes small
+//     tiles or more K slices than a workgroup has waves.  The slices store partial rows and the
+//     RMSNorm kernel that follows adds them in fixed order (kh_gemm.h) - no ticket, no second launch.
 struct PgShape {
   int R, NT, ks, slices;
   bool solo;
+  int kz;
 };
 static const bool pg_solo_env = [] { const char* e = getenv("KH_PG_SOLO"); return !(e && e[0] == '0'); }();
-PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min_blocks, bool quant) {
+static const bool pg_kz_env = [] { const char* e = getenv("KH_PG_KZ"); return !(e && e[0] == '0'); }();
+PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min_blocks, bool quant,
+                 bool allow_kz = false) {
   const int nt_all = (T + 15) / 16;
   const bool wide = nt_all > 8;  // a pass of more than 128 tokens
   static const int cand[4][3] = {{2, 8, 2}, {2, 4, 3}, {2, 2, 4}, {1, 4, 4}};  // R, NT, waves/SIMD that fit
-  PgShape best{1, 4, 1, (nt_all + 3) / 4, false};
+  PgShape best{1, 4, 1, (nt_all + 3) / 4, false, 1};
   double best_cost = -1.0;
   for (const auto& c : cand) {
     const int R = c[0], NT = c[1], occ = c[2];
@@ -289,9 +300,10 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
     if (R == 1 && quant && r2_ok) continue;  // int8: the 32-row tile measured better wherever it fits
     if (NT > 4 && nt_all <= 4) continue;     // no 128-token tile for <= 64 tokens
     const int slices = (nt_all + NT - 1) / NT;
-    const long wgs = (long)(rows_total / (16 * R)) * slices;
+    for (int kz = 1; kz <= (allow_kz && pg_kz_env ? KH_PG_KZ_MAX : 1); kz *= 2)
     for (int ks = 1; ks * nm * 64 <= KH_PG_WG_MAX(quant); ks *= 2) {
-      if (ks > 1 && kblocks / ks < min_blocks) break;  // keep a useful K range per wave
+      const long wgs = (long)(rows_total / (16 * R)) * slices * kz;
+      if (ks * kz > 1 && kblocks / (ks * kz) < min_blocks) break;  // keep a useful K range per wave
       // waves per SIMD on the busiest CU.  A workgroup counts as one wave on EACH SIMD it touches:
       // two 2-wave workgroups on a CU were measured on the same two SIMDs (Llama-3.2-1B, 256 tokens:
       // the (2,8) SwiGLU tile with 2-wave workgroups 255 us against 2 x 83 us for two 128-token
@@ -302,8 +314,9 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
       if (wps > occ) wps = occ;
       const double pen = quant ? (wps <= 1 ? 1.0 : (wps == 2 ? 0.72 : 0.62))
                                : (wps <= 1 ? 1.0 : (wps == 2 ? 1.6 : 1.8));
-      const double per_wave = (double)((kblocks + ks - 1) / ks) * R * NT;
+      const double per_wave = (double)((kblocks + ks * kz - 1) / (ks * kz)) * R * NT;
       double cost = per_wave * (double)(wps * rounds) * pen;
+      cost *= 1.0 + 0.04 * (double)(kz - 1);  // partial rows written, and read back by the RMSNorm
       cost *= 1.0 + 0.15 * (double)(R + NT) / (double)(R * NT);
       // every token slice re-reads the weights from L2 - and, int8, dequantises them again
       cost *= 1.0 + (quant ? 0.15 : 0.05) * (double)(slices - 1);
@@ -319,7 +332,7 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
       }
       if (best_cost < 0 || cost < best_cost) {
         best_cost = cost;
-        best = PgShape{R, NT, ks, slices, solo};
+        best = PgShape{R, NT, ks, slices, solo, kz};
       }
     }
   }
@@ -347,7 +360,7 @@ bool pg_launch_cfg(const PgShape& sh, int tiles, int wg, hipStream_t s, const Kh
         done.push_back({dev, (const void*)kern, lds});
       }
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, sh.slices), dim3(wg), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles, sh.slices, sh.kz), dim3(wg), lds, s, a);
     return true;
   };
   if (sh.R == 2 && sh.NT == 8) return go(k_pg_gemm<Q, 2, 8, EPI>);
@@ -355,30 +368,32 @@ bool pg_launch_cfg(const PgShape& sh, int tiles, int wg, hipStream_t s, const Kh
   if (sh.R == 2) return go(k_pg_gemm<Q, 2, 2, EPI>);
   return go(k_pg_gemm<Q, 1, 4, EPI>);
 }
-// returns whether the QKV epilogue rotates q / k itself (else k_pg_rope has to follow)
+// returns whether the QKV epilogue rotates q / k itself (else k_pg_rope has to follow); RESID: the
+// number of K slices whose partial rows the next RMSNorm has to add (0 = the epilogue added itself)
 template <int EPI>
-bool pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
+int pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
   const bool q = m->cfg.is_quant;
   const int nm = EPI == KH_PG_SWIGLU ? 2 : 1;
-  PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 4 : 16, q);
+  PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 4 : 16, q, EPI == KH_PG_RESID);
   {  // tuning hook: KH_PG_SHAPE_<QKV|RESID|SWIGLU>="R,NT,ks" overrides the heuristic
     static const char* const names[3] = {"KH_PG_SHAPE_QKV", "KH_PG_SHAPE_RESID", "KH_PG_SHAPE_SWIGLU"};
-    static const char* const ov = getenv(names[EPI]);  // read once per process (one static per EPI)
+    const char* const ov = getenv(names[EPI]);  // (per launch: the tests switch it)
     if (ov) {
-      int R = 0, NT = 0, ks = 0;
-      if (sscanf(ov, "%d,%d,%d", &R, &NT, &ks) == 3 && ((R == 2 && (NT == 2 || NT == 4 || NT == 8) && r2_ok) || (R == 1 && NT == 4)) &&
-          (ks == 1 || ks == 2 || ks == 4 || ks == 8) && ks * nm * 64 <= KH_PG_WG_MAX(q))
+      int R = 0, NT = 0, ks = 0, kz = 1;
+      if (sscanf(ov, "%d,%d,%d,%d", &R, &NT, &ks, &kz) >= 3 && ((R == 2 && (NT == 2 || NT == 4 || NT == 8) && r2_ok) || (R == 1 && NT == 4)) &&
+          (ks == 1 || ks == 2 || ks == 4 || ks == 8) && ks * nm * 64 <= KH_PG_WG_MAX(q) &&
+          (kz == 1 || (EPI == KH_PG_RESID && (kz == 2 || kz == 4))))
       {
         const int slices = ((a.T + 15) / 16 + NT - 1) / NT;
         sh = PgShape{R, NT, ks, slices,
-                     !q && (a.T > 128 || R * NT >= 16) && pg_solo_env && (long)(rows_total / (16 * R)) * slices > 256};
+                     !q && (a.T > 128 || R * NT >= 16) && pg_solo_env && (long)(rows_total / (16 * R)) * slices * kz > 256, kz};
       }
     }
   }
   static const bool debug = getenv("KH_PG_DEBUG") != nullptr;
   if (debug)
-    fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d (%d wgs x %d waves%s)\n", EPI,
-            rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, rows_total / (16 * sh.R) * sh.slices,
+    fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d kz %d (%d wgs x %d waves%s)\n", EPI,
+            rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, sh.kz, rows_total / (16 * sh.R) * sh.slices * sh.kz,
             nm * sh.ks, sh.solo ? ", solo" : "");
   if (EPI == KH_PG_QKV && a.rope == KH_PG_ROPE_TILES && (sh.R != 2 || sh.NT > 4))
     a.rope = KH_PG_ROPE_OFF;  // no partner tile in the wave / no registers to hold it: k_pg_rope follows
@@ -386,6 +401,7 @@ bool pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
   const bool ok = q ? pg_launch_cfg<true, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a)
                     : pg_launch_cfg<false, EPI>(sh, tiles, nm * sh.ks * 64, m->stream, a);
   if (!ok) m->pg_launch_failed = true;  // reported by kh_model_prefill_gemm
+  if (EPI == KH_PG_RESID) return sh.kz > 1 ? sh.kz : 0;
   return EPI == KH_PG_QKV && a.rope != KH_PG_ROPE_OFF;
 }
 // forward of T (<= KH_PG_TMAX) prompt tokens at positions pos0..: fills their K/V cache rows
@@ -394,9 +410,11 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
   const bool q = c.is_quant;
   const int tcap = pg_tcap(T);  // token stride of this chunk's tiled slabs
   (void)kh_embedding_f32_host(toks, T, m->tok_emb, m->pg_x, c.dim, c.vocab_size, (void*)m->stream);
+  int pending_kz = 0;  // K slices of the last residual GEMM still to be added to pg_x (by the next RMSNorm)
   auto rmsnorm = [&](const float* w) {
-    if (q) hipLaunchKernelGGL(k_pg_rmsnorm<true>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps, tcap);
-    else hipLaunchKernelGGL(k_pg_rmsnorm<false>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps, tcap);
+    if (q) hipLaunchKernelGGL(k_pg_rmsnorm<true>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps, tcap, (const float*)m->pg_part, pending_kz);
+    else hipLaunchKernelGGL(k_pg_rmsnorm<false>, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_x, w, m->pg_xn, c.dim, c.rms_eps, tcap, (const float*)m->pg_part, pending_kz);
+    pending_kz = 0;
   };
   // attention of the slice: MFMA kernel (kh_pattn.h) unless KH_PG_ATTN=0 or an odd head size
   static const bool attn_env = [] { const char* e = getenv("KH_PG_ATTN"); return !(e && e[0] == '0'); }();
@@ -420,11 +438,14 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       a.rope = !rope_fuse_env ? KH_PG_ROPE_OFF
                : (c.rope_mode == KH_ROPE_HALF ? (c.head_size % 32 == 0 ? KH_PG_ROPE_TILES : KH_PG_ROPE_OFF)
                                               : KH_PG_ROPE_PAIRS);
-      rope_fused = pg_launch<KH_PG_QKV>(m, c.dim + 2 * c.kv_dim, c.dim % 32 == 0 && c.kv_dim % 32 == 0, a);
+      rope_fused = pg_launch<KH_PG_QKV>(m, c.dim + 2 * c.kv_dim, c.dim % 32 == 0 && c.kv_dim % 32 == 0, a) != 0;
     }
     if (!rope_fused)
       hipLaunchKernelGGL(k_pg_rope, dim3(T), dim3(KH_WG), 0, m->stream, m->pg_q, kc, m->sin_cache,
                          m->cos_cache, c.dim, c.kv_dim, c.head_size, pos0, c.rope_mode);
+    // the prompt phase leaves K/V rows and nothing else (no logits): the last layer's K/V rows are
+    // written, its attention, wo and FFN feed nothing (1/L of the pass minus one QKV GEMM)
+    if (l == c.layer_num - 1) break;
     if (mfma_attn) {
       KhPgAttnArgs a{};
       a.q = m->pg_q; a.kc = kc; a.vc = vc; a.out = m->pg_att;
@@ -448,8 +469,8 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       KhPgGemmArgs a{};
       a.w[0] = W.wo;
       a.B = m->pg_att; a.b_tiled = mfma_attn ? 1 : 0; a.tcap = tcap; a.out = m->pg_x;  // decode kernel: row-major rows
-      a.rows0 = c.dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.gshift = m->gshift;
-      pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
+      a.rows0 = c.dim; a.ldo = c.dim; a.K = c.dim; a.T = T; a.gshift = m->gshift; a.part = m->pg_part;
+      pending_kz = pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
     }
     rmsnorm(W.ffn_norm);
     {
@@ -463,8 +484,8 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       KhPgGemmArgs a{};
       a.w[0] = W.w2;
       a.B = m->pg_h; a.b_tiled = 1; a.tcap = tcap; a.out = m->pg_x;
-      a.rows0 = c.dim; a.ldo = c.dim; a.K = c.hidden_dim; a.T = T; a.gshift = m->gshift;
-      pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);
+      a.rows0 = c.dim; a.ldo = c.dim; a.K = c.hidden_dim; a.T = T; a.gshift = m->gshift; a.part = m->pg_part;
+      pending_kz = pg_launch<KH_PG_RESID>(m, c.dim, c.dim % 32 == 0, a);  // (the next layer's RMSNorm adds them)
     }
   }
 }

@@ -25,7 +25,7 @@ for name in sys.argv[2:] or ["llama3.2-1b"]:
     m.time_prefill(toks, 0, "gemm")
     ms = min(m.time_prefill(toks, 0, "gemm") for _ in range(5))
     row = {"label": label, "workload": name, "ms_128": round(ms, 4), "prompt_tok_s": round(128 / ms * 1e3)}
-    for n in (256, 384, 512, 640, 1024):  # longer prompts: weight passes of up to KH_PG_TMAX tokens (KH_PG_CHUNK to A/B)
+    for n in [int(v) for v in os.environ.get("KH_PT_SIZES", "256,384,512,640,1024").split(",") if v]:  # longer prompts: weight passes of up to KH_PG_TMAX tokens (KH_PG_CHUNK to A/B)
         if spec.seq_len >= n:
             lp = [int(t) for t in rng.integers(0, spec.vocab_size, n)]
             m.time_prefill(lp, 0, "gemm")
