@@ -41,7 +41,7 @@ def table(path):
             nm = re.sub(r"\(.*$", "", nm)
             if not nm.startswith(("k_pg_", "k_pf_", "k_emb")):
                 continue
-            key = (nm, f'{r["Grid_Size_X"]}x{r["Grid_Size_Y"]}', r["Workgroup_Size_X"], r["LDS_Block_Size"])
+            key = (nm, f'{r["Grid_Size_X"]}x{r["Grid_Size_Y"]}x{r["Grid_Size_Z"]}', r["Workgroup_Size_X"], r["LDS_Block_Size"])
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             n, s = rows.get(key, (0, 0.0))
             rows[key] = (n + 1, s + d)
