@@ -687,6 +687,37 @@ def test_generate_long_prompt_takes_gemm_prefill(gpu, oracle, name, monkeypatch)
     m.close()
 
 
+@pytest.mark.parametrize("name", ["gqa-half", "int8"])
+def test_gemm_prefill_odd_lengths_vs_bit_exact_path(gpu, name):
+    """Prompt lengths around every seam of the pass logic (1 token, one MFMA token tile +-1, one 128-token
+    slab stride +-1, 256 / 384 / 512 +-1, a full pass plus a remainder): the GEMM prefill against the
+    bit-exact B-token path (itself identical to token-by-token passes) - K/V rows of every layer and the
+    next step's logits and token."""
+    import dataclasses
+    from kuiperllama_amd.model import KuiperModel
+    spec = dataclasses.replace(_PF_SPECS[name], seq_len=1024)
+    img_d = binfmt.synth_image(spec, seed=79, device=gpu)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(11)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, 700)]
+    kv_atol = 2 * KV_ATOL_GEMM * (4 if spec.quant else 1)
+    for n in (1, 15, 16, 17, 127, 129, 255, 257, 383, 385, 511, 513, 640, 699):
+        out = []
+        for mode in ("gemm", "gemv"):
+            m = KuiperModel.from_device_image(img_d, spec)
+            (m.prefill_gemm if mode == "gemm" else m.prefill)(toks[:n], 0)
+            kv = [m.read_kv(layer, 0, n) for layer in range(spec.n_layers)]
+            nxt = m.predict(toks[n], n, exec="fused")
+            out.append((kv, nxt, m.logits().copy()))
+            m.close()
+        (ka, na, la), (kb, nb, lb) = out
+        for layer, ((k1, v1), (k2, v2)) in enumerate(zip(ka, kb)):
+            np.testing.assert_allclose(k1, k2, rtol=0, atol=kv_atol, err_msg=f"{name} n={n} K l{layer}")
+            np.testing.assert_allclose(v1, v2, rtol=0, atol=kv_atol, err_msg=f"{name} n={n} V l{layer}")
+        np.testing.assert_allclose(la, lb, rtol=0, atol=_atol(spec))
+        assert na == nb, n
+
+
 @pytest.mark.parametrize("n", [128, 512])
 @pytest.mark.parametrize("preset", ["llama3.2-1b", "llama2-7b-int8"])
 def test_gemm_prefill_full_size(gpu, oracle, preset, n):
