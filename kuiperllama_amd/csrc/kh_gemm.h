@@ -48,6 +48,13 @@
 // tile of the SwiGLU GEMM in 256 workgroups (pg_shape).  The tiled slabs of a chunk use a token
 // stride `tcap` = its token count rounded up to KH_PG_TSTEP, so a 128-token chunk has exactly the
 // layout it always had.
+// Uniform-ring depth for the (2,8) register tile (64 MFMAs per block; pg_kloop_f32_ring; 0 = the phase scheme).
+// Measured (profiles/r3_prefill_ring28.txt): depth 2 against the phases 0 ... +3 % over four fp32 models
+// (TinyLlama 36.3 -> 37.3 k at 128 tokens, Llama-2-7B fp32 6.97 -> 7.27 k, Llama-3.2-1B unchanged), depth 4
+// about half of that (256 VGPRs), depth 3 does not divide the block counts.
+#ifndef KH_PG_RING_D16
+#define KH_PG_RING_D16 2
+#endif
 #define KH_PG_TMAX 512
 #define KH_PG_TSTEP 128
 #define KH_PG_KZ_MAX 4         // K slices across workgroups of a residual GEMM (partial rows, see KhPgGemmArgs)
@@ -335,9 +342,9 @@ __global__ __launch_bounds__(KH_PG_WG_MAX(QUANT)) void k_pg_gemm(const KhPgGemmA
     } else {
       B = PgBAddr{a.B + (size_t)(tok0 + i) * K + 4 * h, (size_t)16 * K, 16, 0};
     }
-    // small register tiles take the uniform ring (both operands D blocks ahead) when the wave's block
-    // count allows it; the big (2, 8) tile - 64 MFMAs per step - keeps the phase scheme
-    constexpr int RING_D = R * NT <= 8 ? 8 : 0;
+    // the uniform ring (both operands D blocks ahead) when the wave's block count allows it: 8 blocks
+    // deep for the small register tiles, KH_PG_RING_D16 for the big (2, 8) tile; else the phase scheme
+    constexpr int RING_D = R * NT <= 8 ? 8 : KH_PG_RING_D16;
     if constexpr (RING_D > 0) {
       if (b1 - b0 >= 2 * RING_D && (b1 - b0) % RING_D == 0)
         pg_kloop_f32_ring<R, NT, RING_D>(wrow, B, b0, b1, acc);
