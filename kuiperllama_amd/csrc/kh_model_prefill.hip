@@ -266,6 +266,10 @@ int ensure_pg_buffers(kh_model* m) {
 //     dequant between MFMAs, so a second and third wave per SIMD fill the matrix pipe
 //     (profiles/r2_gemm_shape_sweep_7b.txt: (w1,w3) 2 -> 4 waves per workgroup 30.4 -> 23.3 ms per
 //     prefill), up to what the register file admits;
+//     (these penalties were fitted with the phase scheme in every fp32 loop; since the uniform
+//     operand rings of kh_gemm.h a second wave per SIMD costs less - (w1,w3) with 8 instead of 4
+//     waves per workgroup: 3.01 vs 2.75 ms per 128-token pass - but still loses, and a re-sweep of
+//     13 forced shapes leaves every choice of the model in place, profiles/r3_prefill_shapes512.txt);
 //   * bigger register tiles need fewer operand bytes per MFMA (small factor), more token slices
 //     re-read the weights from L2 (small factor), padding tokens are wasted MFMAs;
 //   * fp32 passes of more than 128 tokens launch several times 256 workgroups, which would sit two

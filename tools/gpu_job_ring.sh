@@ -1,4 +1,10 @@
 #!/bin/bash
+# A/B of the uniform-ring depth of the (2,8) prefill GEMM tile against the shipped library.  The experiment
+# libraries are built first (not tracked), e.g. for depth 4:
+#   cd kuiperllama_amd/lib && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off \
+#     -DKH_PG_RING_D16=4 -c ../csrc/kh_model_prefill.hip -o /tmp/pf.o && \
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o exp_ring4.so kh_ops.o kh_model_load.o kh_model_step.o /tmp/pf.o \
+#     kh_model_profile.o kh_tokenizer.o kh_bpe.o        (KH_PG_RING_D16=0 = the phase scheme)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 O=gpurun_out/r3_prefill_ring28b.txt
