@@ -255,6 +255,16 @@ int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t po
  * 64 (int8), int8 group size != 64. */
 int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
 
+/* Launch plans, host-only (no device is touched; for tools and the CPU test-suite).
+ * kh_plan_decode_shapes: {split, u, grid, wg} of the five GEMV kernels of a decode step (qkv, wo, ffn13, w2,
+ * cls) for a geometry - what kh_model_create_* configures (env KH_SHAPE_* overrides included).
+ * kh_plan_prefill_shape: {R, NT, ks, token slices, solo, kz, workgroups} of one GEMM of a T-token prefill
+ * pass (epi 0 = QKV, 1 = residual GEMM wo / w2, 2 = SwiGLU pair; csrc/kh_model_prefill.hip::pg_shape). */
+int kh_plan_decode_shapes(int32_t dim, int32_t hidden_dim, int32_t kv_dim, int32_t vocab_size,
+                          int32_t is_quant, int32_t* out20);
+int kh_plan_prefill_shape(int32_t epi, int32_t T, int32_t rows, int32_t K, int32_t is_quant,
+                          int32_t r2_ok, int32_t* out7);
+
 /* Duration (ms, HIP events on the model stream) of the prompt phase alone for n fed-only tokens:
  * KH_PREFILL_TOKEN = the reference's prompt phase, one forward pass per token (demo/main.cpp:20-22)
  * replayed from the decode hipGraph; KH_PREFILL_GEMV = kh_model_prefill's bit-identical B-token

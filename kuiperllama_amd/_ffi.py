@@ -27,6 +27,7 @@ EXPORTS = [
     "kh_bpe_create_from_file", "kh_bpe_create_from_memory", "kh_bpe_destroy", "kh_bpe_vocab_size",
     "kh_bpe_bos_id", "kh_bpe_eos_id", "kh_bpe_stop_id", "kh_bpe_encode", "kh_bpe_decode",
     "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
+    "kh_plan_decode_shapes", "kh_plan_prefill_shape",
 ]
 
 KH_EXEC_GRAPH, KH_EXEC_FUSED, KH_EXEC_UNFUSED = 0, 1, 2
@@ -119,6 +120,8 @@ def lib() -> C.CDLL:
     L.kh_model_generate_until.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),
                                           _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32)]
     L.kh_model_time_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32)]
+    L.kh_plan_decode_shapes.argtypes = [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
+    L.kh_plan_prefill_shape.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_spm_create_from_file.argtypes = [C.c_char_p, C.POINTER(_vp)]
     L.kh_spm_create_from_memory.argtypes = [_vp, C.c_int64, C.POINTER(_vp)]
     L.kh_spm_destroy.argtypes = [_vp]
@@ -161,3 +164,23 @@ def error_string(code: int) -> str:
 def check(code: int, what: str) -> None:
     if code != 0:
         raise KhError(int(code), what)
+
+
+def plan_decode_shapes(dim: int, hidden_dim: int, kv_dim: int, vocab_size: int, quant: bool) -> dict:
+    """{kernel: {split, u, grid, wg}} of the five decode GEMV kernels for a geometry (host-only)."""
+    out = (_i32 * 20)()
+    rc = lib().kh_plan_decode_shapes(dim, hidden_dim, kv_dim, vocab_size, int(quant), out)
+    if rc != 0:
+        raise KhError(rc, "kh_plan_decode_shapes")
+    names = ("qkv", "wo", "ffn13", "w2", "cls")
+    return {n: dict(zip(("split", "u", "grid", "wg"), out[4 * i:4 * i + 4])) for i, n in enumerate(names)}
+
+
+def plan_prefill_shape(epi: str, T: int, rows: int, K: int, quant: bool, r2_ok: bool = True) -> dict:
+    """Launch plan of one GEMM of a T-token prefill pass (epi: qkv | resid | swiglu); host-only."""
+    out = (_i32 * 7)()
+    rc = lib().kh_plan_prefill_shape({"qkv": 0, "resid": 1, "swiglu": 2}[epi], T, rows, K, int(quant),
+                                     int(r2_ok), out)
+    if rc != 0:
+        raise KhError(rc, "kh_plan_prefill_shape")
+    return dict(zip(("R", "NT", "ks", "slices", "solo", "kz", "workgroups"), out[:]))

@@ -241,16 +241,11 @@ int finish_create(kh_model* m) {
   KH_ALLOC(m->d_token, 1);
   KH_ALLOC(m->d_next, 1);
   // launch geometry
-  m->sh_qkv = pick_shape(c.is_quant, (c.dim + 2 * c.kv_dim) / 2, c.dim, 2, "KH_SHAPE_QKV", KH_WG,
-                         KH_WG_MAX);
-  m->sh_wo = pick_shape(c.is_quant, c.dim / 2, c.dim, 4, "KH_SHAPE_WO", KH_WG, KH_WG_MAX, true);
-  m->sh_ffn = pick_shape(c.is_quant, c.hidden_dim, c.dim, 1, "KH_SHAPE_FFN", KH_WG, KH_WG_MAX);
-  // w2 re-stages the hidden-sized input in every workgroup: 512-thread workgroups halve that
-  // L2 -> LDS traffic for the same number of waves (measured 14.1 -> 11.8 us on Llama-3.2-1B)
-  m->sh_w2 = pick_shape(c.is_quant, c.dim / 2, c.hidden_dim, 4, "KH_SHAPE_W2", KH_WG_MAX, KH_WG_MAX,
-                        true);
-  m->sh_cls = pick_shape(c.is_quant, (c.vocab_size + 1) / 2, c.dim, 1, "KH_SHAPE_CLS",
-                         c.is_quant ? KH_WG : KH_WG_MAX, KH_WG_MAX);
+  {
+    kh_model::Shape sh[5];
+    plan_decode_shapes(c.is_quant != 0, c.dim, c.hidden_dim, c.kv_dim, c.vocab_size, sh);
+    m->sh_qkv = sh[0]; m->sh_wo = sh[1]; m->sh_ffn = sh[2]; m->sh_w2 = sh[3]; m->sh_cls = sh[4];
+  }
   m->nparts = m->sh_cls.grid;
   if (getenv("KH_SHAPE_DEBUG")) {
     const struct { const char* n; const kh_model::Shape* s; } all[] = {

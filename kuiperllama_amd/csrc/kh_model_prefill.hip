@@ -495,6 +495,22 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
 }
 }  // namespace
 
+// Host-only view of the prefill GEMM launch plan (pg_shape) for tools and the CPU test-suite: epi 0 = QKV
+// (rows = dim + 2 kv_dim), 1 = residual GEMM (wo / w2: rows = dim), 2 = SwiGLU pair (rows = hidden_dim); K =
+// contraction length; r2_ok = the 32-row register tile divides the row blocks.  out[7] = {R, NT, ks, token
+// slices, solo, kz, workgroups}.  No device is touched; the KH_PG_SHAPE_* overrides are not applied.
+extern "C" int kh_plan_prefill_shape(int32_t epi, int32_t T, int32_t rows, int32_t K, int32_t is_quant,
+                                     int32_t r2_ok, int32_t* out7) {
+  if (!out7 || epi < 0 || epi > 2 || T <= 0 || T > KH_PG_TMAX || rows <= 0 || K <= 0) return KH_ERR_INVALID_ARG;
+  const bool q = is_quant != 0;
+  if (rows % 16 || K % (q ? 64 : 16)) return KH_ERR_UNSUPPORTED;
+  const PgShape sh = pg_shape(T, rows, r2_ok != 0, epi == KH_PG_SWIGLU ? 2 : 1, K / (q ? 64 : 16), q ? 4 : 16, q,
+                              epi == KH_PG_RESID);
+  out7[0] = sh.R; out7[1] = sh.NT; out7[2] = sh.ks; out7[3] = sh.slices; out7[4] = sh.solo ? 1 : 0; out7[5] = sh.kz;
+  out7[6] = rows / (16 * sh.R) * sh.slices * sh.kz;
+  return KH_OK;
+}
+
 extern "C" int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0) {
   if (!m || !h_tokens || n <= 0 || pos0 < 0) return KH_ERR_INVALID_ARG;
   const kh_config& c = m->cfg;

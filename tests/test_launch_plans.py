@@ -1,0 +1,104 @@
+"""Host-side launch planning (no GPU): the decode GEMV shapes (csrc/kh_model_step.hip::pick_shape) and the
+prefill GEMM shapes (csrc/kh_model_prefill.hip::pg_shape) through the host-only C-ABI entries
+kh_plan_decode_shapes / kh_plan_prefill_shape.  Invariants every plan must satisfy for every BASELINE
+geometry, plus the plans DESIGN.md documents (so that a change of the heuristics shows up here and not
+only as a slower GPU run)."""
+import itertools
+
+import pytest
+
+from kuiperllama_amd import _ffi, binfmt
+
+PRESETS = ["llama3.2-1b", "llama2-7b", "llama2-7b-int8", "qwen2.5-0.5b", "tinyllama-1.1b"]
+
+
+@pytest.mark.parametrize("name", PRESETS)
+def test_decode_plan_invariants(name):
+    sp = binfmt.PRESETS[name]
+    plan = _ffi.plan_decode_shapes(sp.dim, sp.hidden_dim, sp.kv_dim, sp.vocab_size, sp.quant)
+    rows = {"qkv": sp.dim + 2 * sp.kv_dim, "wo": sp.dim, "ffn13": 2 * sp.hidden_dim, "w2": sp.dim,
+            "cls": sp.vocab_size}
+    cols = {"qkv": sp.dim, "wo": sp.dim, "ffn13": sp.dim, "w2": sp.hidden_dim, "cls": sp.dim}
+    max_split = {"qkv": 2, "wo": 4, "ffn13": 1, "w2": 4, "cls": 1}
+    for k, s in plan.items():
+        assert s["split"] in (1, 2, 4) and s["split"] <= max_split[k], (k, s)
+        assert s["u"] in ((2, 4) if sp.quant else (2, 4, 8)), (k, s)
+        assert s["wg"] in (256, 512), (k, s)
+        assert 1 <= s["grid"] <= 1024, (k, s)  # never more than 4 x 256-thread workgroups per CU
+        # a split part still streams a useful number of bytes per row pair
+        elem = 1 if sp.quant else 4
+        assert s["split"] == 1 or 2 * cols[k] * elem // s["split"] >= (4096 if sp.quant else 8192), (k, s)
+        # the grid never exceeds the work: one workgroup handles >= one row pair per wave group
+        pairs_per_wg = (s["wg"] // 64) // s["split"]
+        pairs = (rows[k] // 2 + 1) // 2 if k == "ffn13" else (rows[k] + 1) // 2
+        assert s["grid"] <= -(-max(pairs, 1) // pairs_per_wg) or s["grid"] % 256 == 0, (k, s)
+
+
+def test_decode_plan_documented_shapes(monkeypatch):
+    """The shapes DESIGN.md 3.2 quotes for the two bench workloads."""
+    for k in ("QKV", "WO", "FFN", "W2", "CLS"):
+        monkeypatch.delenv("KH_SHAPE_" + k, raising=False)
+    sp = binfmt.PRESETS["llama2-7b-int8"]
+    plan = _ffi.plan_decode_shapes(sp.dim, sp.hidden_dim, sp.kv_dim, sp.vocab_size, True)
+    assert plan["qkv"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
+    assert plan["wo"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
+    assert plan["ffn13"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
+    assert plan["w2"] == {"split": 2, "u": 2, "grid": 512, "wg": 512}
+    assert plan["cls"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
+    sp = binfmt.PRESETS["llama3.2-1b"]
+    plan = _ffi.plan_decode_shapes(sp.dim, sp.hidden_dim, sp.kv_dim, sp.vocab_size, False)
+    assert plan["ffn13"] == {"split": 1, "u": 8, "grid": 512, "wg": 256}  # the roofline kernel of bench.py
+    assert plan["w2"]["wg"] == 512 and plan["cls"]["wg"] == 512
+    # the tuning hook is honoured, and a malformed value is ignored
+    monkeypatch.setenv("KH_SHAPE_FFN", "1,4,256")
+    assert _ffi.plan_decode_shapes(sp.dim, sp.hidden_dim, sp.kv_dim, sp.vocab_size, False)["ffn13"] == \
+        {"split": 1, "u": 4, "grid": 256, "wg": 256}
+    monkeypatch.setenv("KH_SHAPE_FFN", "3,4,256")
+    assert _ffi.plan_decode_shapes(sp.dim, sp.hidden_dim, sp.kv_dim, sp.vocab_size, False)["ffn13"] == plan["ffn13"]
+
+
+@pytest.mark.parametrize("name", PRESETS)
+def test_prefill_plan_invariants(name):
+    sp = binfmt.PRESETS[name]
+    kq = 64 if sp.quant else 16
+    gemms = [("qkv", sp.dim + 2 * sp.kv_dim, sp.dim, sp.dim % 32 == 0 and sp.kv_dim % 32 == 0),
+             ("resid", sp.dim, sp.dim, sp.dim % 32 == 0), ("resid", sp.dim, sp.hidden_dim, sp.dim % 32 == 0),
+             ("swiglu", sp.hidden_dim, sp.dim, sp.hidden_dim % 32 == 0)]
+    for (epi, rows, K, r2), T in itertools.product(gemms, (1, 16, 17, 64, 100, 128, 129, 256, 300, 384, 512)):
+        p = _ffi.plan_prefill_shape(epi, T, rows, K, sp.quant, r2)
+        nm = 2 if epi == "swiglu" else 1
+        assert (p["R"], p["NT"]) in ((2, 8), (2, 4), (2, 2), (1, 4)), (epi, T, p)
+        assert p["R"] == 1 or r2
+        assert p["slices"] * p["NT"] * 16 >= T and (p["slices"] - 1) * p["NT"] * 16 < T, (epi, T, p)
+        assert p["slices"] * p["NT"] * 16 <= -(-T // 128) * 128  # inside the slab stride of the pass
+        assert p["ks"] in (1, 2, 4, 8) and p["ks"] * nm * 64 <= 512, (epi, T, p)
+        assert p["kz"] in (1, 2, 4) and (p["kz"] == 1 or epi == "resid"), (epi, T, p)
+        # every wave keeps a useful K range (fp32: 16 blocks of 16 columns; int8: 4 blocks of 64)
+        assert p["ks"] * p["kz"] == 1 or (K // kq) // (p["ks"] * p["kz"]) >= (4 if sp.quant else 16), (epi, T, p)
+        assert p["workgroups"] == rows // (16 * p["R"]) * p["slices"] * p["kz"]
+        # one workgroup per CU at a time: fp32 launches of more than 256 workgroups only
+        assert not p["solo"] or (not sp.quant and p["workgroups"] > 256), (epi, T, p)
+
+
+def test_prefill_plan_documented_shapes(monkeypatch):
+    """Llama-3.2-1B, DESIGN.md 3.5: a 512-token pass puts every GEMM on the big tile; a 128-token pass splits
+    the K range of wo / w2 across two workgroups; KH_PG_KZ=0 / KH_PG_SOLO=0 are read at load time and are not
+    exercised here."""
+    sp = binfmt.PRESETS["llama3.2-1b"]
+    f = lambda epi, T, rows, K: _ffi.plan_prefill_shape(epi, T, rows, K, False, True)  # noqa: E731
+    assert f("swiglu", 128, sp.hidden_dim, sp.dim) == dict(R=2, NT=8, ks=2, slices=1, solo=0, kz=1, workgroups=256)
+    assert f("swiglu", 512, sp.hidden_dim, sp.dim) == dict(R=2, NT=8, ks=2, slices=4, solo=1, kz=1, workgroups=1024)
+    for K in (sp.dim, sp.hidden_dim):
+        assert f("resid", 512, sp.dim, K) == dict(R=2, NT=8, ks=4, slices=4, solo=0, kz=1, workgroups=256)
+        p = f("resid", 128, sp.dim, K)
+        assert p["kz"] == 2 and p["workgroups"] == 256 and p["solo"] == 0
+    assert f("qkv", 512, sp.dim + 2 * sp.kv_dim, sp.dim)["solo"] == 1
+    # Llama-2-7B fp32, 128 tokens: four-wave workgroups, one per CU at a time (was 344 two-wave workgroups)
+    s7 = binfmt.PRESETS["llama2-7b"]
+    p = f("swiglu", 128, s7.hidden_dim, s7.dim)
+    assert (p["R"], p["NT"], p["ks"], p["solo"]) == (2, 8, 2, 1)
+    # argument errors
+    with pytest.raises(_ffi.KhError):
+        _ffi.plan_prefill_shape("qkv", 513, 3072, 2048, False, True)
+    with pytest.raises(_ffi.KhError):
+        _ffi.plan_prefill_shape("qkv", 128, 3072, 2040, False, True)
