@@ -172,7 +172,11 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 #endif
 #define KH_ATTN_MAX_NS 16
 #define KH_ATTN_TLONG_DEFAULT 4096  // pos + 1 from which GQA models switch to the group path
-#define KH_ATTN_MAX_NS_G 32          // splits per KV group (the last arriver merges them all)
+#ifndef KH_ATTN_MAX_NS_G
+// splits per KV group (the last arriver merges them all).  48 / 64 (two workgroups per CU) measured far worse
+// from position 16383 on: 22.6 -> 34-35 us, 93.9 -> 110-120 us at 131071 (profiles/r3_attn_nsg.txt)
+#define KH_ATTN_MAX_NS_G 32
+#endif
 #define KH_ATTN_MIN_GROUPS 4         // fewer KV heads than this: too few workgroups, stay per-head
 static inline size_t attn_fast_lds_bytes(int head_size, int wg = KH_WG) {
   return (size_t)(8 + 8 + (wg / KH_WAVE) * head_size) * sizeof(float);
