@@ -173,8 +173,8 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 #define KH_ATTN_MAX_NS 16
 #define KH_ATTN_TLONG_DEFAULT 4096  // pos + 1 from which GQA models switch to the group path
 #ifndef KH_ATTN_MAX_NS_G
-// splits per KV group (the last arriver merges them all).  48 / 64 (two workgroups per CU) measured far worse
-// from position 16383 on: 22.6 -> 34-35 us, 93.9 -> 110-120 us at 131071 (profiles/r3_attn_nsg.txt)
+// splits per KV group (the last arriver merges them all).  16 / 24 / 48 / 64 measured: 48 / 64 (two workgroups per CU) far worse
+// from position 16383 on: 22.6 -> 34-35 us, 93.9 -> 110-120 us at 131071 ; 16 / 24 lose from 32767 on (profiles/r3_attn_nsg.txt)
 #define KH_ATTN_MAX_NS_G 32
 #endif
 #define KH_ATTN_MIN_GROUPS 4         // fewer KV heads than this: too few workgroups, stay per-head
