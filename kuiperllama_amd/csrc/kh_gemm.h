@@ -48,6 +48,9 @@
 // tile of the SwiGLU GEMM in 256 workgroups (pg_shape).  The tiled slabs of a chunk use a token
 // stride `tcap` = its token count rounded up to KH_PG_TSTEP, so a 128-token chunk has exactly the
 // layout it always had.
+#define KH_PG_TMAX 512
+#define KH_PG_TSTEP 128
+#define KH_PG_KZ_MAX 4         // K slices across workgroups of a residual GEMM (partial rows, see KhPgGemmArgs)
 // Uniform-ring depth for the (2,8) register tile (64 MFMAs per block; pg_kloop_f32_ring; 0 = the phase scheme).
 // Measured (profiles/r3_prefill_ring28.txt): depth 2 against the phases 0 ... +3 % over four fp32 models
 // (TinyLlama 36.3 -> 37.3 k at 128 tokens, Llama-2-7B fp32 6.97 -> 7.27 k, Llama-3.2-1B unchanged), depth 4
@@ -55,9 +58,6 @@
 #ifndef KH_PG_RING_D16
 #define KH_PG_RING_D16 2
 #endif
-#define KH_PG_TMAX 512
-#define KH_PG_TSTEP 128
-#define KH_PG_KZ_MAX 4         // K slices across workgroups of a residual GEMM (partial rows, see KhPgGemmArgs)
 // Workgroup width: <= 8 waves.  The fp32 shapes use 4 (ONE wave per SIMD, see pg_shape); int8 up to 8
 // (its dequant VALU work wants a partner wave on the SIMD to keep the matrix pipe busy).
 #define KH_PG_WG_MAX_F32 512
@@ -508,8 +508,28 @@ __global__ __launch_bounds__(KH_WG) void k_pg_rmsnorm(float* __restrict__ X,
   f32x4* x4 = (f32x4*)(X + (size_t)t * dim);
   const f32x4* w4 = (const f32x4*)w;
   const int n4 = dim >> 2;
+  // the row (after the deferred residual add) stays in registers between the two passes for dim <= 4096
+  // (KEEP float4 per thread); longer rows re-read what this thread wrote
+  constexpr int KEEP = 4;
+  f32x4 keep[KEEP];
   float ss = 0.f;
-  for (int k = threadIdx.x; k < n4; k += KH_WG) {
+#pragma unroll
+  for (int i = 0; i < KEEP; ++i) {
+    const int k = (int)threadIdx.x + i * KH_WG;
+    if (k < n4) {
+      f32x4 v = x4[k];
+      if (kz > 0) {
+        for (int z = 0; z < kz; ++z) {
+          const f32x4 p = *(const f32x4*)(part + ((size_t)z * tcap + t) * dim + 4 * k);
+          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        x4[k] = v;
+      }
+      keep[i] = v;
+      ss = fma4(v, v, ss);
+    }
+  }
+  for (int k = (int)threadIdx.x + KEEP * KH_WG; k < n4; k += KH_WG) {
     f32x4 v = x4[k];
     if (kz > 0) {
       for (int z = 0; z < kz; ++z) {
@@ -522,15 +542,21 @@ __global__ __launch_bounds__(KH_WG) void k_pg_rmsnorm(float* __restrict__ X,
   }
   ss = block_sum(ss, red);
   const float rs = 1.0f / sqrtf(ss / (float)dim + eps);
-  for (int k = threadIdx.x; k < n4; k += KH_WG) {
-    const f32x4 v = x4[k], g = w4[k];
+  auto emit = [&](int k, const f32x4& v) __attribute__((always_inline)) {
+    const f32x4 g = w4[k];
     f32x4 o;
     o.x = g.x * (rs * v.x);
     o.y = g.y * (rs * v.y);
     o.z = g.z * (rs * v.z);
     o.w = g.w * (rs * v.w);
     *(f32x4*)(Xn + pg_tiled_index(QUANT, 4 * k, t, tcap)) = o;
+  };
+#pragma unroll
+  for (int i = 0; i < KEEP; ++i) {
+    const int k = (int)threadIdx.x + i * KH_WG;
+    if (k < n4) emit(k, keep[i]);
   }
+  for (int k = (int)threadIdx.x + KEEP * KH_WG; k < n4; k += KH_WG) emit(k, x4[k]);
 }
 
 // RoPE of the T query rows and of the T fresh key rows, in place (cpu/rope_kernel.cpp:18-42 half,
