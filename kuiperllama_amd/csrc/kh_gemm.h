@@ -27,10 +27,15 @@
 //   * C/D: lane (j, hq = l>>4) holds rows 4hq..4hq+3 of a tile for token j: a float4 of four
 //     consecutive output rows of one token, which is exactly what the epilogues store.
 //   * a workgroup = ks waves that split K (fixed-order LDS reduction, deterministic), times two
-//     for the (w1, w3) SwiGLU pair; blockIdx.y selects a slice of 16*NT tokens.  (R, NT, ks) are
-//     chosen per GEMM so that every launch has >= ~1 wave per SIMD.
-//   * weights arrive in phases through two register rings (see pg_phases), the activation operand
-//     ping-pongs one step ahead.
+//     for the (w1, w3) SwiGLU pair; blockIdx.y selects a slice of 16*NT tokens.  (R, NT, ks, kz) are
+//     chosen per GEMM by the cost model of kh_model_prefill.hip::pg_shape (one wave per SIMD for
+//     fp32, two or three for int8; launches above 256 workgroups one workgroup per CU at a time).
+//   * operand feeding: the fp32 loops request weights AND activations of block b + D together when
+//     block b has been consumed (pg_kloop_f32_ring, D = 8 for the small tiles, 2 for the (2,8) tile);
+//     the int8 loops - and fp32 K ranges a ring does not divide - take the weights in phases through
+//     two register rings with the activation operand ping-ponging one step ahead (pg_phases).
+//   * blockIdx.z (residual GEMMs only) = K slice ACROSS workgroups: partial rows, added by the
+//     RMSNorm kernel that follows (KhPgGemmArgs::part).
 // int8 (group 64): the lane's 16-byte load is 16 consecutive weights of one 64-group; they are
 // converted once to scale * float(w) - the reference's per-element dequant (cuda/matmul_kernel.cu:73)
 // - and feed 16 MFMAs per token tile.  Its tiled activation layout is [K/64][4][128][4][4] (the
