@@ -21,7 +21,7 @@ for name in sys.argv[2:] or ["llama3.2-1b"]:
     torch.cuda.synchronize()
     rng = np.random.default_rng(0)
     toks = [int(t) for t in rng.integers(0, spec.vocab_size, 128)]
-    m = KuiperModel.from_device_image(img, spec, max_seq_len=min(spec.seq_len, 2048))
+    m = KuiperModel.from_device_image(img, spec, max_seq_len=min(spec.seq_len, int(os.environ.get("KH_PT_MAXSEQ", "2048"))))
     m.time_prefill(toks, 0, "gemm")
     ms = min(m.time_prefill(toks, 0, "gemm") for _ in range(5))
     row = {"label": label, "workload": name, "ms_128": round(ms, 4), "prompt_tok_s": round(128 / ms * 1e3)}
