@@ -162,8 +162,11 @@ typedef struct kh_model_opts {
   float rms_eps;       /* 1e-5 / 1e-6 (QWEN2) */
   int32_t max_seq_len; /* rows of KV cache + sin/cos to allocate; 0 = header seq_len */
   int32_t device;      /* HIP device ordinal (reference: cudaSetDevice(0)) */
-  int32_t flags;       /* reserved, 0 */
+  int32_t flags;       /* KH_FLAG_* bits, 0 = defaults */
 } kh_model_opts;
+/* decode attention at positions that need several time splits: merge the split partials inside the
+ * attention launch (ticket + last arriver) instead of in the wo kernel that follows (the default) */
+#define KH_FLAG_ATTN_MERGE_IN_LAUNCH 1
 
 typedef struct kh_config {
   int32_t dim, hidden_dim, layer_num, head_num, kv_head_num, vocab_size, seq_len;
@@ -264,6 +267,16 @@ int kh_plan_decode_shapes(int32_t dim, int32_t hidden_dim, int32_t kv_dim, int32
                           int32_t is_quant, int32_t* out20);
 int kh_plan_prefill_shape(int32_t epi, int32_t T, int32_t rows, int32_t K, int32_t is_quant,
                           int32_t r2_ok, int32_t* out7);
+
+/* Tuning / test hooks.  Every hook the library honours (KH_SHAPE_<QKV|WO|FFN|W2|CLS>, KH_ATTN_WG,
+ * KH_ATTN_TLONG, KH_ATTN_DEFER, KH_PREFILL, KH_PG_<CHUNK|SHAPE_*|SOLO|KZ|ATTN|ATTN_QT|ROPE_FUSE|DEBUG>,
+ * KH_SHAPE_DEBUG) lives in ONE process-wide key -> value table, seeded once from the KH_* variables of
+ * the environment when the library is first used and changed afterwards only through kh_debug_set
+ * (value NULL = unset).  No launch path reads the environment.  Hooks that shape a model (KH_SHAPE_*,
+ * KH_ATTN_*) are read by kh_model_create_*; the others by the call they affect.  Keys must start with "KH_". */
+int kh_debug_set(const char* key, const char* value);
+const char* kh_debug_get(const char* key); /* NULL when unset */
+int64_t kh_debug_list(char* buf, int64_t cap); /* '\n'-separated names; returns bytes needed */
 
 /* Duration (ms, HIP events on the model stream) of the prompt phase alone for n fed-only tokens:
  * KH_PREFILL_TOKEN = the reference's prompt phase, one forward pass per token (demo/main.cpp:20-22)

@@ -28,11 +28,13 @@ EXPORTS = [
     "kh_bpe_bos_id", "kh_bpe_eos_id", "kh_bpe_stop_id", "kh_bpe_encode", "kh_bpe_decode",
     "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
     "kh_plan_decode_shapes", "kh_plan_prefill_shape",
+    "kh_debug_set", "kh_debug_get", "kh_debug_list",
 ]
 
 KH_EXEC_GRAPH, KH_EXEC_FUSED, KH_EXEC_UNFUSED = 0, 1, 2
 KH_NUM_KCLASS = 7
 KH_ERR_RANGE = -6
+KH_FLAG_ATTN_MERGE_IN_LAUNCH = 1
 
 
 class KhError(RuntimeError):
@@ -151,10 +153,46 @@ def lib() -> C.CDLL:
     L.kh_model_profile_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32), C.POINTER(_i32)]
     L.kh_kclass_name.argtypes = [C.c_int]
     L.kh_kclass_name.restype = C.c_char_p
+    L.kh_debug_set.argtypes = [C.c_char_p, C.c_char_p]
+    L.kh_debug_get.argtypes = [C.c_char_p]
+    L.kh_debug_get.restype = C.c_char_p
+    L.kh_debug_list.argtypes = [C.c_char_p, _i64]
+    L.kh_debug_list.restype = _i64
     for name in EXPORTS:  # fail at load time, not at first call, if a symbol is missing
         getattr(L, name)
     _lib = L
     return L
+
+
+def debug_set(key: str, value: Optional[str]) -> None:
+    """Set (or with None: clear) one tuning / test hook of the library (kh_debug_set)."""
+    check(lib().kh_debug_set(key.encode(), None if value is None else str(value).encode()), "kh_debug_set")
+
+
+def debug_get(key: str) -> Optional[str]:
+    v = lib().kh_debug_get(key.encode())
+    return None if v is None else v.decode()
+
+
+_HOOK_PREFIXES = ("KH_SHAPE_", "KH_ATTN_", "KH_PG_", "KH_PREFILL")
+
+
+def sync_env() -> None:
+    """Mirror the KH_* hook variables of os.environ into the library's hook table.
+
+    The library reads the environment once, when it is loaded; afterwards hooks change only through
+    kh_debug_set.  The Python binding calls this before every entry point that reads a hook, so
+    `os.environ[...] = ...` / `monkeypatch.setenv` keep working in tests and tools."""
+    L = lib()
+    need = L.kh_debug_list(None, 0)
+    buf = C.create_string_buffer(int(need))
+    L.kh_debug_list(buf, need)
+    have = {k for k in buf.value.decode().split("\n") if k.startswith(_HOOK_PREFIXES)}
+    want = {k: v for k, v in os.environ.items() if k.startswith(_HOOK_PREFIXES)}
+    for k in have - set(want):
+        L.kh_debug_set(k.encode(), None)
+    for k, v in want.items():
+        L.kh_debug_set(k.encode(), v.encode())
 
 
 def error_string(code: int) -> str:
@@ -168,6 +206,7 @@ def check(code: int, what: str) -> None:
 
 def plan_decode_shapes(dim: int, hidden_dim: int, kv_dim: int, vocab_size: int, quant: bool) -> dict:
     """{kernel: {split, u, grid, wg}} of the five decode GEMV kernels for a geometry (host-only)."""
+    sync_env()
     out = (_i32 * 20)()
     rc = lib().kh_plan_decode_shapes(dim, hidden_dim, kv_dim, vocab_size, int(quant), out)
     if rc != 0:
@@ -178,6 +217,7 @@ def plan_decode_shapes(dim: int, hidden_dim: int, kv_dim: int, vocab_size: int, 
 
 def plan_prefill_shape(epi: str, T: int, rows: int, K: int, quant: bool, r2_ok: bool = True) -> dict:
     """Launch plan of one GEMM of a T-token prefill pass (epi: qkv | resid | swiglu); host-only."""
+    sync_env()
     out = (_i32 * 7)()
     rc = lib().kh_plan_prefill_shape({"qkv": 0, "resid": 1, "swiglu": 2}[epi], T, rows, K, int(quant),
                                      int(r2_ok), out)

@@ -14,6 +14,8 @@
 // the output over its timesteps, then timestep-groups are folded with shuffles + one LDS
 // exchange across the 4 waves.
 #pragma once
+#include <stdlib.h>
+
 #include "kh_common.h"
 
 #define KH_ATTN_TC 2048  // timesteps per LDS score chunk (8 KiB)
@@ -158,12 +160,21 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 // Long contexts: the grid carries NS workgroups per head ("splits"); at run time the first
 // nact = ceil((pos+1)/TS) of them each take TS timesteps (TS >= 256, so positions < 256 use
 // exactly one workgroup per head and none of the machinery below) and the rest exit.  With
-// nact > 1 every split publishes its unnormalised (M, L, o[hs]) and takes a ticket; the LAST
-// arriver merges all partials — the in-launch split reduction recipe of the CDNA guide
-// (plain stores -> every wave drains vmcnt -> barrier -> one lane: agent release fence + asm
-// vmcnt(0) -> relaxed agent ticket; last arriver: agent acquire -> barrier -> reads), which is
-// placement-independent (splits of a head land on different XCDs) and never waits on another
-// workgroup, so it cannot hang.  The ticket counter is re-armed by the merger.
+// nact > 1 every split leaves its unnormalised (M, L, o[hs]) in the workspace.  Two ways to combine them:
+//  * DEFERRED (the fused decode step between position 256 and the GQA group path): the split
+//    workgroups store and STOP; the kernel that consumes the attention output anyway (wo,
+//    kh_fused.h::k_wo_comb) combines the <= 16 partials of every head in fixed order while it stages
+//    its input vector.  No ticket, no fence, no last arriver: the kernel boundary that exists already
+//    carries the visibility (r3: 12.8 us per layer at pos 4095, of which ~9 were the publish -> ticket ->
+//    acquire -> merge chain).  The host picks this pair of kernels per captured graph from the
+//    position range the graph covers (kh_model_step.hip::step_variant); the arithmetic is the in-launch
+//    merger's, bit for bit.
+//  * IN-LAUNCH (operator entry points, prefill slices, the GQA group path whose 32 splits per group
+//    are too many to re-read in every wo workgroup): publish with agent-scope write-through stores
+//    (global_store sc1: no release fence, guide G16 R1), every storing wave drains vmcnt, barrier, one
+//    lane takes a relaxed agent ticket; the LAST arriver merges with agent-scope loads (sc1: served
+//    past L1, so no acquire fence either).  Placement-independent (splits of a head land on different
+//    XCDs) and never waits on another workgroup, so it cannot hang.  The merger re-arms the ticket.
 #ifndef KH_ATTN_UB
 #define KH_ATTN_UB 4
 #endif
@@ -348,13 +359,21 @@ __device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h,
   return num / den;
 }
 
+// agent-scope relaxed store = global_store ... sc1 (write-through): visible to every XCD once the
+// issuing wave's vmcnt has drained, without a buffer_wbl2
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One workgroup = (head h, split s) of a grid of heads*NS workgroups.  ws may be null iff NS==1.
+// defer: leave the partial in the workspace and return, whatever nact is (the consumer combines).
 // Returns true in the workgroup that wrote the head's final output.
 template <int G>
 __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const float* k_base,
                                                       const float* v_base, int kv_stride, int hs,
                                                       int pos, float* out_h, float* smem, int h,
-                                                      int s, int NS, AttnSplitWs ws, int NSW = 0) {
+                                                      int s, int NS, AttnSplitWs ws, int NSW = 0,
+                                                      bool defer = false) {
   if (NSW <= 0) NSW = NS;  // slot stride of the workspace (>= NS)
   const int tid = threadIdx.x;
   const int nT = pos + 1;
@@ -366,30 +385,33 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
   float r, L;
   const float M = attn_fast_partial<G>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end, smem,
                                        r, L);
+  const size_t slot = (size_t)h * NSW + s;
+  if (defer) {  // plain stores (also with ONE active split); the next kernel on the stream reads them
+    if (tid < hs) ws.o[slot * hs + tid] = r;
+    if (tid == 0) {
+      ws.ml[slot * 2] = M;
+      ws.ml[slot * 2 + 1] = L;
+    }
+    return false;
+  }
   if (nact == 1) {
     if (tid < hs) out_h[tid] = r / L;
     return true;
   }
-  // ---- publish this split's partial, take a ticket ---------------------------------------
-  const size_t slot = (size_t)h * NSW + s;
-  if (tid < hs) ws.o[slot * hs + tid] = r;
+  // ---- publish this split's partial (write-through), take a ticket ------------------------------
+  if (tid < hs) st_agent(&ws.o[slot * hs + tid], r);
   if (tid == 0) {
-    ws.ml[slot * 2] = M;
-    ws.ml[slot * 2 + 1] = L;
+    st_agent(&ws.ml[slot * 2], M);
+    st_agent(&ws.ml[slot * 2 + 1], L);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
   __syncthreads();
   int* flag = (int*)smem;  // red[] is free again after the barriers inside attn_fast_partial
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wait the compiler may drop (guide G16)
+  if (tid == 0)
     flag[0] = __hip_atomic_fetch_add(&ws.cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   __syncthreads();
   if (flag[0] != nact - 1) return false;  // not the last arriver
-  // ---- last arriver: merge every split's partial ----------------------------------------------
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
+  // ---- last arriver: merge every split's partial (agent-scope loads inside) ------------------------
   if (tid < hs) {
     out_h[tid] = attn_merge_splits(ws, h, tid, hs, nact, NSW);
   }
@@ -550,26 +572,21 @@ __device__ __forceinline__ void attn_group_decode(const float* q_g, const float*
     return;
   }
   const size_t slot = (size_t)h * NSW + s;
-  if (mine) {
-    ws.o[slot * hs + e] = r;
+  if (mine) {  // write-through publication, see attn_head_decode_fast
+    st_agent(&ws.o[slot * hs + e], r);
     if (e == 0) {
-      ws.ml[slot * 2] = M;
-      ws.ml[slot * 2 + 1] = L;
+      st_agent(&ws.ml[slot * 2], M);
+      st_agent(&ws.ml[slot * 2 + 1], L);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
   __syncthreads();
   int* flag = (int*)smem;
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0)
     flag[0] = __hip_atomic_fetch_add(&ws.cnt[g * KVM], 1, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
-  }
   __syncthreads();
   if (flag[0] != nact - 1) return;  // not the last arriver
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
   if (mine) out_g[(size_t)j * hs + e] = attn_merge_splits(ws, h, e, hs, nact, NSW);
   if (tid == 0)
     __hip_atomic_store(&ws.cnt[g * KVM], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -590,6 +607,7 @@ struct KhAttnArgs {
   int ws_stride;           // split slots per head in the workspace (>= nsplit, >= nsplit_g)
   int nsplit_g;            // GQA long-context path: kv_heads * nsplit_g workgroups (0 = off)
   int t_long;              // the group path runs when pos + 1 >= t_long
+  int defer;               // per-head path: leave the split partials (also a single one) for k_wo_comb
   // prefill (kh_prefill.h): gridDim.y tokens per launch, token t at position pos + t, its q /
   // out rows tok_stride floats apart, its split workspace ws_tok_bytes apart (decode: y = 1)
   int tok_stride;
@@ -608,7 +626,7 @@ __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem
   attn_head_decode_fast<G>(
       a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
       a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, smem, h, s, a.nsplit,
-      attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), a.ws_stride);
+      attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), a.ws_stride, a.defer != 0);
 }
 
 // KVM = 0: per-head workgroups only.  KVM = kv_mul > 1: per-head workgroups at short contexts,
@@ -658,6 +676,51 @@ static inline bool attn_group_supported(int head_size, int kv_mul, int wg) {
   if (G == 32) return kv_mul == 2 || kv_mul == 4;
   return false;
 }
+// Split geometry of the decode launch for a cache of `cache_len` rows: the ONE place that decides it
+// (model level: kh_model_load.hip::finish_create; operator level: kh_mha_decode_f32).
+//   ns      time splits per head on the per-head path (1 for head_size <= 32: generic kernel)
+//   ns_g    splits per KV group on the GQA group path, 0 = path off
+//   stride  split slots per head in the workspace
+//   t_long  the group path runs when pos + 1 >= t_long
+// t_long_override < 0: default policy - models with few KV heads (Qwen2.5-0.5B: 2) cannot fill the chip
+// with (group, split) workgroups and stay per-head; 0 = never; > 0 = that threshold.
+struct AttnPlan {
+  int ns, ns_g, stride, t_long;
+};
+static inline AttnPlan attn_plan(int head_num, int kv_mul, int head_size, int cache_len, int wg,
+                                 int t_long_override) {
+  AttnPlan p;
+  p.ns = head_size > 32 ? attn_num_splits(cache_len) : 1;
+  p.ns_g = 0;
+  p.stride = p.ns;
+  p.t_long = 1 << 30;
+  if (kv_mul > 1 && head_size > 32 && head_num % kv_mul == 0 &&
+      attn_group_supported(head_size, kv_mul, wg)) {
+    int tl = head_num / kv_mul >= KH_ATTN_MIN_GROUPS ? KH_ATTN_TLONG_DEFAULT : 0;
+    if (t_long_override >= 0) tl = t_long_override;
+    if (tl > 0 && tl <= cache_len) {
+      p.ns_g = attn_group_splits(cache_len, head_num / kv_mul);
+      p.t_long = tl;
+      if (p.ns_g > p.stride) p.stride = p.ns_g;
+    }
+  }
+  return p;
+}
+// Deferred merge (defer mode above): can the consumer's staging combine the partials?  The combiner
+// (kh_fused.h::CombStager) keeps wo's input vector in registers (<= 16 floats per thread of a `wg`-wide
+// workgroup), computes the heads * KH_ATTN_MAX_NS merge coefficients in <= 4 passes of the workgroup and
+// maps a float4 of the vector to its head with a shift (power-of-two head sizes).
+#define KH_COMB_CP 4
+static inline bool comb_supported(int dim, int heads, int head_size, int wg) {
+  return head_size > 32 && (head_size & (head_size - 1)) == 0 && dim == heads * head_size && dim <= 16 * wg &&
+         heads * KH_ATTN_MAX_NS <= KH_COMB_CP * wg;
+}
+// KH_ATTN_TLONG hook -> t_long_override
+static inline int attn_tlong_hook() {
+  const char* e = khm::dbg("KH_ATTN_TLONG");
+  return e ? atoi(e) : -1;
+}
+
 // Launch.  a.nsplit_g == 0 disables the group path; head_size > 32 required (callers route
 // smaller heads to the generic LDS-score kernel).
 // pos_hi >= 0 (host-positioned launches only): the highest position among the ntok tokens; the grid

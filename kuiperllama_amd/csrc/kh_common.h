@@ -33,6 +33,17 @@ static inline int kh_launch_status() {
 
 static inline bool kh_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Tuning / test hooks (KH_SHAPE_*, KH_PREFILL, KH_PG_*, ...): looked up in the process-wide table of
+// kh_debug.cpp (seeded once from the KH_* environment variables, changed through kh_debug_set()).
+// nullptr when the hook is not set.  Host code only.
+namespace khm {
+const char* dbg(const char* key);
+inline bool dbg_off(const char* key) {  // hook present and starting with '0'
+  const char* e = dbg(key);
+  return e && e[0] == '0';
+}
+}  // namespace khm
+
 // Weight rows are streamed exactly once per token: non-temporal loads keep them from
 // displacing the activations in L2 (MI355X guide: nt-weights row).
 template <typename T>

@@ -182,19 +182,17 @@ struct KhGemvResArgs {
   float* x;          // [K] residual stream, updated in place
   int M, K, gshift;
 };
-template <bool QUANT, int U, int MAXV, int SPLIT>
-__global__ __launch_bounds__(KH_WG_MAX, 4) void k_gemv_res(const KhGemvResArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+// STAGER(a, M): the staging of the input vector - Stager<false, ...> over a.vec, or CombStager over the
+// split partials of a deferring attention launch (k_wo_comb below).
+template <bool QUANT, int U, int SPLIT, class St>
+__device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, St& st, f32x4* xs, float* red) {
   // scalar locals for everything the lambdas touch (see qkv_body)
   const void* const w = a.w.w;
   const float* const scales = a.w.scales;
   float* const x = a.x;
   const int M = a.M;
-  f32x4* xs = (f32x4*)smem_raw;
-  float* red = lds_red_ptr<QUANT>(xs, M);
   const int lane = threadIdx.x & 63;
   const Gemv<QUANT, U> g(M, a.gshift);
-  Stager<false, QUANT, MAXV> st(a.vec, nullptr, M);
   auto pair = [&](int p) __attribute__((always_inline)) { return g.rows(w, 2 * p, w, 2 * p + 1, scales, scales, M); };
   struct Aux {
     float x0, x1;
@@ -209,6 +207,177 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_gemv_res(const KhGemvResArgs a
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
+}
+template <bool QUANT, int U, int MAXV, int SPLIT>
+__global__ __launch_bounds__(KH_WG_MAX, 4) void k_gemv_res(const KhGemvResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  f32x4* xs = (f32x4*)smem_raw;
+  Stager<false, QUANT, MAXV> st(a.vec, nullptr, a.M);
+  gemv_res_body<QUANT, U, SPLIT>(a, st, xs, lds_red_ptr<QUANT>(xs, a.M));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deferred merge of the decode-attention time splits (kh_attn.h, defer mode), done by the kernel that
+// consumes the attention output anyway: while wo stages its input vector it reads, per head, the
+// nact <= 16 partials (M_s, L_s, o_s[hs]) the split workgroups left in the workspace and forms
+//     att[h][e] = (sum_s o_s[e] f_s) / (sum_s L_s f_s) ,   f_s = exp(M_s - max_k M_k)
+// with both sums as fmaf chains in ascending s - the arithmetic of the in-launch merger
+// (kh_attn.h::attn_merge_splits), bit for bit, so the two ways of merging are interchangeable; one
+// active split gives o / L, the value the attention kernel itself writes when it is not deferring.
+// The factors f_s are computed once per workgroup (16 lanes per head: DPP max) and parked in LDS beside
+// the L_s; the o loads do not depend on them, so the (M, L) loads, the first batch of o loads and the
+// first weight tile of gemv_pairs all leave before the first wait: one or two L2 round trips under the
+// first HBM round trip, against the ~9 us of publish -> ticket -> acquire -> merge the in-launch form
+// costs the attention kernel (r3 profile, pos 4095).
+// This is a kernel of its own, not a branch inside k_gemv_res: with both stagings behind a uniform
+// branch the compiler's s_waitcnt bookkeeping merged their counter states and the weight loop of the
+// PLAIN path lost its progressive vmcnt ladder (seen in the ISA).  Which one a step launches is decided
+// on the host from the position range of the captured graph (kh_model_step.hip::step_variant).
+struct KhCombArgs {
+  const float* ml;        // [heads, nsw, 2]  (M, L) per (head, split slot)
+  const float* o;         // [heads, nsw, hs] unnormalised outputs
+  const int32_t* d_pos;
+  int ns;                 // time splits per head carried by the attention grid (<= KH_ATTN_MAX_NS)
+  int nsw;                // split slots per head in the workspace
+  int heads, hs;
+};
+// MAXV float4 of the vector per thread (as Stager); SB splits per batch of o loads.
+template <bool LAYOUT_Q8, int MAXV, int SB>
+struct CombStager {
+  static_assert(KH_ATTN_MAX_NS == 16, "factor slots are laid out 16 per head");
+  f32x4 ov[SB * MAXV];
+  float cm[KH_COMB_CP], cl[KH_COMB_CP];
+  const float* ml;
+  const f32x4* o4;
+  float* fl;  // LDS: f[heads * 16] | L[heads * 16]
+  int M, hs4, hsh, nact, nsw, heads;
+  __device__ __forceinline__ CombStager(const KhCombArgs& c, int M_, int nact_, float* fl_)
+      : ml(c.ml), o4((const f32x4*)c.o), fl(fl_), M(M_), hs4(c.hs >> 2), nact(nact_), nsw(c.nsw), heads(c.heads) {
+    hsh = __builtin_ctz((unsigned)hs4);  // float4 index -> head: head sizes are powers of two (comb_supported)
+  }
+  __device__ __forceinline__ int head_of(int i) const { return i >> hsh; }
+  __device__ __forceinline__ void load_batch(int s0) {
+    const int M4 = M >> 2;
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int s = s0 + u < nact ? s0 + u : nact - 1;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int i = threadIdx.x + v * kh_wg();
+        const int ci = i < M4 ? i : 0;
+        const int h = head_of(ci);
+        ov[u * MAXV + v] = o4[(size_t)(h * nsw + s) * hs4 + (ci - h * hs4)];
+      }
+    }
+  }
+  __device__ __forceinline__ void issue() {
+#pragma unroll
+    for (int c = 0; c < KH_COMB_CP; ++c) {  // (M, L) of (head, split) = (t >> 4, t & 15)
+      const int t = threadIdx.x + c * kh_wg();
+      const int h = t >> 4, s = t & 15;
+      const bool ok = h < heads && s < nact;
+      const size_t idx = ok ? (size_t)(h * nsw + s) * 2 : 0;
+      cm[c] = ml[idx];
+      cl[c] = ml[idx + 1];
+    }
+    load_batch(0);
+  }
+  __device__ __forceinline__ void finish(f32x4* xs, float /*eps*/, float* /*red*/) {
+    const int nf = heads * 16;
+#pragma unroll
+    for (int c = 0; c < KH_COMB_CP; ++c) {
+      const int t = threadIdx.x + c * kh_wg();
+      const int h = t >> 4, s = t & 15;
+      const bool ok = h < heads && s < nact;
+      const float mm = ok ? cm[c] : -INFINITY;
+      const float Mx = group_max<16>(mm);  // all 64 lanes: DPP, no branch
+      if (h < heads) {
+        fl[t] = ok ? expf(mm - Mx) : 0.f;
+        fl[nf + t] = ok ? cl[c] : 0.f;
+      }
+    }
+    __syncthreads();
+    const int M4 = M >> 2, M16 = M >> 4;
+    f32x4 num[MAXV];
+    float den[MAXV];
+    int hb[MAXV];
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      num[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      den[v] = 0.f;
+      const int i = threadIdx.x + v * kh_wg();
+      hb[v] = head_of(i < M4 ? i : 0) << 4;
+    }
+    for (int s0 = 0;;) {
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        if (s0 + u < nact) {  // uniform
+#pragma unroll
+          for (int v = 0; v < MAXV; ++v) {
+            const float f = fl[hb[v] + s0 + u];
+            const float l = fl[nf + hb[v] + s0 + u];
+            const f32x4 t = ov[u * MAXV + v];
+            num[v].x = __builtin_fmaf(t.x, f, num[v].x);
+            num[v].y = __builtin_fmaf(t.y, f, num[v].y);
+            num[v].z = __builtin_fmaf(t.z, f, num[v].z);
+            num[v].w = __builtin_fmaf(t.w, f, num[v].w);
+            den[v] = __builtin_fmaf(l, f, den[v]);
+          }
+        }
+      }
+      s0 += SB;
+      if (s0 >= nact) break;
+      load_batch(s0);
+    }
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = threadIdx.x + v * kh_wg();
+      if (i < M4) {
+        f32x4 r;
+        r.x = num[v].x / den[v];
+        r.y = num[v].y / den[v];
+        r.z = num[v].z / den[v];
+        r.w = num[v].w / den[v];
+        xs[LAYOUT_Q8 ? q8_slot(i, M16) : i] = r;
+      }
+    }
+    __syncthreads();
+  }
+};
+// xs | red | comb | f[heads * 16] | L[heads * 16]
+static inline size_t comb_lds_bytes(bool quant, int M, int heads) {
+  return fused_lds_bytes(quant, M) + (size_t)2 * heads * KH_ATTN_MAX_NS * sizeof(float);
+}
+struct KhWoCombArgs {
+  KhGemvResArgs g;  // g.vec unused
+  KhCombArgs cb;
+};
+// wo behind a deferring attention launch.  MAXV in {2, 4} float4 of the dim-long vector per thread.
+template <bool QUANT, int U, int MAXV, int SPLIT>
+__global__ __launch_bounds__(KH_WG_MAX, 4) void k_wo_comb(const KhWoCombArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  f32x4* xs = (f32x4*)smem_raw;
+  float* red = lds_red_ptr<QUANT>(xs, a.g.M);
+  const int nact = attn_active_splits(*a.cb.d_pos, a.cb.ns);
+  float* fl = red + 3 * KH_WAVES_MAX;
+  // The o loads travel beside the first weight tile where both fit the 128 registers of a
+  // 4-waves-per-SIMD launch (4 splits x 2 float4 or 2 x 4 per batch).  A 64-register tile (fp32 U = 8) or
+  // the int8 tile beside 4 float4 per split does not leave that room (scratch in the first build): there
+  // the vector is staged completely, 16 float4 per batch, before gemv_pairs requests its first tile.
+  constexpr bool OVERLAP = !(U >= 8 || (QUANT && U >= 4 && MAXV >= 4));
+  if constexpr (OVERLAP) {
+    CombStager<QUANT, MAXV, (MAXV >= 4 ? 2 : 4)> st(a.cb, a.g.M, nact, fl);
+    gemv_res_body<QUANT, U, SPLIT>(a.g, st, xs, red);
+  } else {
+    CombStager<QUANT, MAXV, 16 / MAXV> st(a.cb, a.g.M, nact, fl);
+    st.issue();
+    st.finish(xs, 0.f, red);
+    struct Staged {
+      __device__ __forceinline__ void issue() {}
+      __device__ __forceinline__ void finish(f32x4*, float, float*) {}
+    } none;
+    gemv_res_body<QUANT, U, SPLIT>(a.g, none, xs, red);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -52,6 +52,8 @@ struct kh_model {
   int attn_ws_stride = 1;   // split slots per head in attn_ws
   int attn_t_long = 1 << 30;
   int attn_wg = KH_WG;
+  bool attn_defer = false;  // variant 1 exists: split partials combined by kh_fused.h::k_wo_comb
+  int step_var = 0;         // variant the launch_* helpers use right now (set by launch_step_fused / profile)
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
   int seq_cap = 0;  // capacity of d_forced / d_words
@@ -78,8 +80,14 @@ struct kh_model {
   // the decode step captured once as a 1-step graph and once as a KH_GRAPH_STEPS-step graph:
   // consecutive hipGraphLaunch calls leave the GPU idle for ~8 us (measured), so the long
   // graph amortises that gap over several tokens
-  hipGraph_t graph = nullptr, graphN = nullptr;
-  hipGraphExec_t gexec = nullptr, gexecN = nullptr;
+  // ... each in two VARIANTS of the attention / wo pair (kh_model_step.hip::step_variant): 0 = the
+  // attention launch merges its time splits itself (valid at every position; nothing to merge below
+  // position 256), 1 = the splits are merged by k_wo_comb (positions on the per-head path only)
+  struct StepGraph {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t e = nullptr;
+  };
+  StepGraph sg1[2], sgN[2];  // [variant]: one step, KH_GRAPH_STEPS steps
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -102,17 +110,21 @@ int configure_step_kernels(kh_model* m);  // >64 KiB dynamic-LDS opt-in of the h
 KhAttnArgs fill_attn(kh_model* m, int l);
 void launch_qkv(kh_model* m, int l);
 void launch_attn(kh_model* m, int l);
-void launch_wo(kh_model* m, int l);
+void launch_wo(kh_model* m, int l);  // follows m->step_var like launch_attn
 void launch_ffn13(kh_model* m, int l);
 void launch_w2(kh_model* m, int l);
 void launch_cls(kh_model* m);
 void launch_sample(kh_model* m, int advance, int n_forced);
-void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev);
+// variant (see kh_model::sg1): which attention / wo pair the launches of a step use
+int step_variant(const kh_model* m, int pos_lo, int pos_hi);
+void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev, int variant);
 int launch_step_unfused(kh_model* m, int pos);
 void set_state(kh_model* m, int token, int pos);
 int ensure_pinned_words(kh_model* m, int n);
 int ensure_seq_cap(kh_model* m, int n);
-int ensure_graph(kh_model* m, int n_forced);
+void destroy_step_graphs(kh_model* m);
+// the captured graph of 1 (steps8 = false) or KH_GRAPH_STEPS decode steps in `variant`, captured on first use
+int step_graph(kh_model* m, int n_forced, int variant, bool steps8, hipGraphExec_t* out);
 // ---- kh_model_prefill.hip -------------------------------------------------------------------
 bool prefill_supported(const kh_model* m);  // B-token VALU path
 bool pg_supported(const kh_model* m);       // MFMA GEMM path

@@ -247,32 +247,27 @@ int finish_create(kh_model* m) {
     m->sh_qkv = sh[0]; m->sh_wo = sh[1]; m->sh_ffn = sh[2]; m->sh_w2 = sh[3]; m->sh_cls = sh[4];
   }
   m->nparts = m->sh_cls.grid;
-  if (getenv("KH_SHAPE_DEBUG")) {
+  if (dbg("KH_SHAPE_DEBUG")) {
     const struct { const char* n; const kh_model::Shape* s; } all[] = {
         {"qkv", &m->sh_qkv}, {"wo", &m->sh_wo}, {"ffn13", &m->sh_ffn}, {"w2", &m->sh_w2}, {"cls", &m->sh_cls}};
     for (const auto& e : all)
       fprintf(stderr, "[kh] shape %-5s split %d u %d grid %d wg %d\n", e.n, e.s->split, e.s->u, e.s->grid, e.s->wg);
   }
-  m->attn_ns = c.head_size > 32 ? attn_num_splits(c.cache_len) : 1;
   // attention: 8 waves per (head, split) shorten each lane's timestep loop
   m->attn_wg = KH_WG_MAX;
-  if (const char* e = getenv("KH_ATTN_WG"))
+  if (const char* e = dbg("KH_ATTN_WG"))
     if (atoi(e) == 256 || atoi(e) == 512) m->attn_wg = atoi(e);
-  // GQA long-context path (kh_attn.h): one workgroup per (kv group, split) from pos + 1 >=
-  // t_long on; KH_ATTN_TLONG overrides the threshold (0 = never)
-  m->attn_ws_stride = m->attn_ns;
-  if (c.kv_mul > 1 && c.head_size > 32 &&
-      attn_group_supported(c.head_size, c.kv_mul, m->attn_wg)) {
-    // default policy: models with few KV heads (Qwen2.5-0.5B: 2) cannot fill the chip with
-    // (group, split) workgroups and stay per-head; an explicit KH_ATTN_TLONG overrides
-    int t_long = c.kv_head_num >= KH_ATTN_MIN_GROUPS ? KH_ATTN_TLONG_DEFAULT : 0;
-    if (const char* e = getenv("KH_ATTN_TLONG")) t_long = atoi(e);
-    if (t_long > 0 && t_long <= (int)c.cache_len) {
-      m->attn_ns_g = attn_group_splits(c.cache_len, c.kv_head_num);
-      m->attn_t_long = t_long;
-      if (m->attn_ns_g > m->attn_ws_stride) m->attn_ws_stride = m->attn_ns_g;
-    }
+  {
+    const AttnPlan ap = attn_plan(c.head_num, c.kv_mul, c.head_size, c.cache_len, m->attn_wg, attn_tlong_hook());
+    m->attn_ns = ap.ns;
+    m->attn_ns_g = ap.ns_g;
+    m->attn_ws_stride = ap.stride;
+    m->attn_t_long = ap.t_long;
   }
+  // step variant 1 - time splits merged by k_wo_comb instead of a last arriver (kh_attn.h, kh_fused.h) -
+  // needs wo's in-register staging (dim <= 16 floats per thread) and heads * 16 factor slots per pass
+  m->attn_defer = m->attn_ns > 1 && !(m->opts.flags & KH_FLAG_ATTN_MERGE_IN_LAUNCH) && !dbg_off("KH_ATTN_DEFER") &&
+                  comb_supported(c.dim, c.head_num, c.head_size, m->sh_wo.wg);
   if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride)) {
     KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
     KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));
@@ -342,10 +337,7 @@ int new_model(const int32_t* h_header, const kh_model_opts* opts, kh_model** out
 extern "C" void kh_model_destroy(kh_model* m) {
   if (!m) return;
   if (m->stream) (void)hipStreamSynchronize(m->stream);
-  if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
-  if (m->gexecN) (void)hipGraphExecDestroy(m->gexecN);
-  if (m->graph) (void)hipGraphDestroy(m->graph);
-  if (m->graphN) (void)hipGraphDestroy(m->graphN);
+  destroy_step_graphs(m);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   for (void* q : {(void*)m->pf_x, (void*)m->pf_q, (void*)m->pf_att, (void*)m->pf_h, m->pf_ws,

@@ -190,6 +190,7 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
     if (l == c.layer_num - 1) break;
     {
       KhAttnArgs a = fill_attn(m, l);
+      a.defer = 0;  // multi-token slices merge in the launch
       a.q = m->pf_q;
       a.out = m->pf_att;
       a.d_pos = nullptr;
@@ -247,12 +248,20 @@ int ensure_pg_buffers(kh_model* m) {
   if ((rc = zalloc(&m->pg_att, T * c.dim)) != KH_OK) return rc;
   if ((rc = zalloc(&m->pg_h, T * c.hidden_dim)) != KH_OK) return rc;
   if ((rc = zalloc(&m->pg_part, (size_t)KH_PG_KZ_MAX * T * c.dim)) != KH_OK) return rc;  // K-slice partial rows
-  m->pg_ws_tok_bytes = (attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride) + 255) & ~(size_t)255;
-  if (m->pg_ws_tok_bytes) {
-    KH_CHECK_HIP(hipMalloc(&m->pg_ws, m->pg_ws_tok_bytes * T));
-    KH_CHECK_HIP(hipMemsetAsync(m->pg_ws, 0, m->pg_ws_tok_bytes * T, m->stream));
-  }
   m->pg_ready = true;
+  return KH_OK;
+}
+// does the prompt-slice attention run on the MFMA kernel (kh_pattn.h)?  KH_PG_ATTN=0 forces the fallback.
+bool pg_mfma_attn(const kh_model* m) { return !dbg_off("KH_PG_ATTN") && pg_attn_supported(m->cfg.head_size); }
+// The split workspace of the decode-attention FALLBACK (one per token of a pass, ~270 KB per token at
+// Llama-3.2-1B geometry: 136 MB for a 512-token pass).  Every BASELINE head size has an MFMA
+// instantiation, so it is allocated on the first pass that actually takes the fallback.
+int ensure_pg_ws(kh_model* m) {
+  if (m->pg_ws || pg_mfma_attn(m)) return KH_OK;
+  m->pg_ws_tok_bytes = (attn_ws_bytes(m->cfg.head_num, m->cfg.head_size, m->attn_ws_stride) + 255) & ~(size_t)255;
+  if (!m->pg_ws_tok_bytes) return KH_OK;
+  KH_CHECK_HIP(hipMalloc(&m->pg_ws, m->pg_ws_tok_bytes * (size_t)KH_PG_TMAX));
+  KH_CHECK_HIP(hipMemsetAsync(m->pg_ws, 0, m->pg_ws_tok_bytes * (size_t)KH_PG_TMAX, m->stream));
   return KH_OK;
 }
 // Launch shape of one prefill GEMM (kh_gemm.h): R 16-row tiles and NT 16-token tiles per wave,
@@ -289,8 +298,9 @@ struct PgShape {
   bool solo;
   int kz;
 };
-static const bool pg_solo_env = [] { const char* e = getenv("KH_PG_SOLO"); return !(e && e[0] == '0'); }();
-static const bool pg_kz_env = [] { const char* e = getenv("KH_PG_KZ"); return !(e && e[0] == '0'); }();
+// hooks read per call (kh_debug_set takes effect on the next launch plan)
+static inline bool pg_solo_on() { return !dbg_off("KH_PG_SOLO"); }
+static inline bool pg_kz_on() { return !dbg_off("KH_PG_KZ"); }
 PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min_blocks, bool quant,
                  bool allow_kz = false) {
   const int nt_all = (T + 15) / 16;
@@ -304,7 +314,7 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
     if (R == 1 && quant && r2_ok) continue;  // int8: the 32-row tile measured better wherever it fits
     if (NT > 4 && nt_all <= 4) continue;     // no 128-token tile for <= 64 tokens
     const int slices = (nt_all + NT - 1) / NT;
-    for (int kz = 1; kz <= (allow_kz && pg_kz_env ? KH_PG_KZ_MAX : 1); kz *= 2)
+    for (int kz = 1; kz <= (allow_kz && pg_kz_on() ? KH_PG_KZ_MAX : 1); kz *= 2)
     for (int ks = 1; ks * nm * 64 <= KH_PG_WG_MAX(quant); ks *= 2) {
       const long wgs = (long)(rows_total / (16 * R)) * slices * kz;
       if (ks * kz > 1 && kblocks / (ks * kz) < min_blocks) break;  // keep a useful K range per wave
@@ -326,7 +336,7 @@ PgShape pg_shape(int T, int rows_total, bool r2_ok, int nm, int kblocks, int min
       cost *= 1.0 + (quant ? 0.15 : 0.05) * (double)(slices - 1);
       cost *= (double)(slices * NT) / (double)nt_all;
       bool solo = false;
-      if (!quant && (wide || R * NT >= 16) && pg_solo_env && wgs > 256) {
+      if (!quant && (wide || R * NT >= 16) && pg_solo_on() && wgs > 256) {
         const long wg_wps = (nm * ks + 3) / 4;
         const double c1 = per_wave * (double)(((wgs + 255) / 256) * wg_wps) * (wg_wps <= 1 ? 1.0 : (wg_wps == 2 ? 1.6 : 1.8));
         if (c1 < per_wave * (double)(wps * rounds) * pen) {
@@ -381,7 +391,7 @@ int pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
   PgShape sh = pg_shape(a.T, rows_total, r2_ok, nm, a.K / (q ? 64 : 16), q ? 4 : 16, q, EPI == KH_PG_RESID);
   {  // tuning hook: KH_PG_SHAPE_<QKV|RESID|SWIGLU>="R,NT,ks" overrides the heuristic
     static const char* const names[3] = {"KH_PG_SHAPE_QKV", "KH_PG_SHAPE_RESID", "KH_PG_SHAPE_SWIGLU"};
-    const char* const ov = getenv(names[EPI]);  // (per launch: the tests switch it)
+    const char* const ov = dbg(names[EPI]);
     if (ov) {
       int R = 0, NT = 0, ks = 0, kz = 1;
       if (sscanf(ov, "%d,%d,%d,%d", &R, &NT, &ks, &kz) >= 3 && ((R == 2 && (NT == 2 || NT == 4 || NT == 8) && r2_ok) || (R == 1 && NT == 4)) &&
@@ -390,12 +400,11 @@ int pg_launch(kh_model* m, int rows_total, bool r2_ok, KhPgGemmArgs a) {
       {
         const int slices = ((a.T + 15) / 16 + NT - 1) / NT;
         sh = PgShape{R, NT, ks, slices,
-                     !q && (a.T > 128 || R * NT >= 16) && pg_solo_env && (long)(rows_total / (16 * R)) * slices * kz > 256, kz};
+                     !q && (a.T > 128 || R * NT >= 16) && pg_solo_on() && (long)(rows_total / (16 * R)) * slices * kz > 256, kz};
       }
     }
   }
-  static const bool debug = getenv("KH_PG_DEBUG") != nullptr;
-  if (debug)
+  if (dbg("KH_PG_DEBUG"))
     fprintf(stderr, "[pg] epi %d rows %d K %d T %d -> R %d NT %d slices %d ks %d kz %d (%d wgs x %d waves%s)\n", EPI,
             rows_total, a.K, a.T, sh.R, sh.NT, sh.slices, sh.ks, sh.kz, rows_total / (16 * sh.R) * sh.slices * sh.kz,
             nm * sh.ks, sh.solo ? ", solo" : "");
@@ -421,9 +430,8 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
     pending_kz = 0;
   };
   // attention of the slice: MFMA kernel (kh_pattn.h) unless KH_PG_ATTN=0 or an odd head size
-  static const bool attn_env = [] { const char* e = getenv("KH_PG_ATTN"); return !(e && e[0] == '0'); }();
-  const bool mfma_attn = attn_env && pg_attn_supported(c.head_size);
-  static const bool rope_fuse_env = [] { const char* e = getenv("KH_PG_ROPE_FUSE"); return !(e && e[0] == '0'); }();
+  const bool mfma_attn = pg_mfma_attn(m);
+  const bool rope_fuse_env = !dbg_off("KH_PG_ROPE_FUSE");
   for (int l = 0; l < c.layer_num; ++l) {
     const LayerW& W = m->layers[l];
     float* kc = m->kcache + (size_t)l * c.cache_len * c.kv_dim;
@@ -458,6 +466,7 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
       launch_pg_attn(a, c.head_size, m->stream);
     } else {
       KhAttnArgs a = fill_attn(m, l);
+      a.defer = 0;  // multi-token slices merge in the launch
       a.q = m->pg_q;
       a.out = m->pg_att;
       a.d_pos = nullptr;
@@ -521,10 +530,11 @@ extern "C" int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
   int rc;
   if ((rc = ensure_pg_buffers(m)) != KH_OK) return rc;
+  if ((rc = ensure_pg_ws(m)) != KH_OK) return rc;
   m->pg_launch_failed = false;
   // tuning / test hook: KH_PG_CHUNK=<tokens per weight pass> (16 .. KH_PG_TMAX), read per call
   int chunk = KH_PG_TMAX;
-  if (const char* e = getenv("KH_PG_CHUNK")) {
+  if (const char* e = dbg("KH_PG_CHUNK")) {
     const int v = atoi(e);
     chunk = v < 16 ? 16 : (v > KH_PG_TMAX ? KH_PG_TMAX : v);
   }
@@ -595,17 +605,22 @@ extern "C" int kh_model_time_prefill(kh_model* m, const int32_t* h_tokens, int32
                                 hipMemcpyHostToDevice, m->stream));
     KH_CHECK_HIP(hipStreamSynchronize(m->stream));
     const int n_forced = m->seq_cap + 1;
-    if ((rc = ensure_graph(m, n_forced)) != KH_OK) return rc;
+    // capture (first use) outside the timed region
+    hipGraphExec_t ge = nullptr;
+    for (int s = 0; s < n;) {
+      const bool n8 = n - s >= KH_GRAPH_STEPS;
+      const int k = n8 ? KH_GRAPH_STEPS : 1;
+      if ((rc = step_graph(m, n_forced, step_variant(m, pos0 + s, pos0 + s + k - 1), n8, &ge)) != KH_OK) return rc;
+      s += k;
+    }
     set_state(m, h_tokens[0], pos0);
     KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
     for (int s = 0; s < n;) {
-      if (n - s >= KH_GRAPH_STEPS) {
-        KH_CHECK_HIP(hipGraphLaunch(m->gexecN, m->stream));
-        s += KH_GRAPH_STEPS;
-      } else {
-        KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
-        s += 1;
-      }
+      const bool n8 = n - s >= KH_GRAPH_STEPS;
+      const int k = n8 ? KH_GRAPH_STEPS : 1;
+      if ((rc = step_graph(m, n_forced, step_variant(m, pos0 + s, pos0 + s + k - 1), n8, &ge)) != KH_OK) return rc;
+      KH_CHECK_HIP(hipGraphLaunch(ge, m->stream));
+      s += k;
     }
     KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
   } else if (mode == KH_PREFILL_GEMV) {
@@ -617,6 +632,7 @@ extern "C" int kh_model_time_prefill(kh_model* m, const int32_t* h_tokens, int32
   } else if (mode == KH_PREFILL_GEMM) {
     if (!pg_supported(m)) return KH_ERR_UNSUPPORTED;
     if ((rc = ensure_pg_buffers(m)) != KH_OK) return rc;
+    if ((rc = ensure_pg_ws(m)) != KH_OK) return rc;
     KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
     if ((rc = kh_model_prefill_gemm(m, h_tokens, n, pos0)) != KH_OK) return rc;
     KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));

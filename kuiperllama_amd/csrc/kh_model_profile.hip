@@ -14,6 +14,7 @@ extern "C" int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos,
   if (pos < 0 || pos >= c.cache_len) return KH_ERR_RANGE;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
   set_state(m, 1 % c.vocab_size, pos);
+  m->step_var = step_variant(m, pos, pos);  // the attention / wo pair a step at `pos` launches
   const bool per_layer = kclass < KH_K_CLS;
   const int n_inner = per_layer ? c.layer_num : 1;
   auto sweep = [&]() {
@@ -65,11 +66,12 @@ extern "C" int kh_model_time_step(kh_model* m, int32_t pos, int32_t reps, float*
   // (re)capture the step graph if that replaced them
   int rc;
   if ((rc = ensure_seq_cap(m, pos + 1)) != KH_OK) return rc;
-  if ((rc = ensure_graph(m, m->seq_cap + 1)) != KH_OK) return rc;
+  hipGraphExec_t ge = nullptr;
+  if ((rc = step_graph(m, m->seq_cap + 1, step_variant(m, pos, pos), false, &ge)) != KH_OK) return rc;
   for (int r = 0; r < reps; ++r) {
     set_state(m, 1 % m->cfg.vocab_size, pos);
     KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
-    KH_CHECK_HIP(hipGraphLaunch(m->gexec, m->stream));
+    KH_CHECK_HIP(hipGraphLaunch(ge, m->stream));
     KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
     KH_CHECK_HIP(hipEventSynchronize(m->ev1));
     float ms = 0.f;
@@ -100,7 +102,7 @@ extern "C" int kh_model_profile_step(kh_model* m, int32_t start_pos, int32_t n_s
   set_state(m, 1 % c.vocab_size, start_pos);
   int rc = KH_OK;
   for (int s = 0; s < n_steps && rc == KH_OK; ++s) {
-    launch_step_fused(m, 1, 0, ev.data());
+    launch_step_fused(m, 1, 0, ev.data(), step_variant(m, start_pos + s, start_pos + s));
     hipError_t e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) {
       rc = (int)e;

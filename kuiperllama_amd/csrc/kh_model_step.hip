@@ -25,7 +25,7 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
   kh_model::Shape sh;
   sh.wg = wg;
   // tuning hook (tools/sweep_shapes.py): KH_SHAPE_<K>="split,u,grid[,wg]" overrides the heuristic
-  if (const char* ov = env ? getenv(env) : nullptr) {
+  if (const char* ov = env ? dbg(env) : nullptr) {
     int sp = 0, u = 0, g = 0, w = wg;
     const int nf = sscanf(ov, "%d,%d,%d,%d", &sp, &u, &g, &w);
     if (nf >= 3 && (sp == 1 || sp == 2 || sp == 4) && sp <= max_split &&
@@ -206,6 +206,7 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   a.ws_stride = m->attn_ws_stride;
   a.nsplit_g = m->attn_ns_g;
   a.t_long = m->attn_t_long;
+  a.defer = m->step_var == 1 ? 1 : 0;
   a.tok_stride = 0;
   a.ws_tok_bytes = 0;
   return a;
@@ -236,11 +237,46 @@ KhGemvResArgs fill_wo(kh_model* m, int l) {
   a.gshift = m->gshift;
   return a;
 }
+// wo behind a deferring attention launch (step variant 1): in-register staging of 2 or 4 float4
+#define KH_L5C(Q, UU, MV, SP, GRID, LDS, STREAM, ARGS) \
+  hipLaunchKernelGGL((k_wo_comb<Q, UU, MV, SP>), dim3(GRID), dim3(kh_launch_wg), LDS, STREAM, ARGS)
+#define KH_SEL_SP5C(Q, UU, MV, SP, ...)                     \
+  do {                                                      \
+    if ((SP) == 4)                                          \
+      KH_L5C(Q, UU, MV, 4, __VA_ARGS__);                    \
+    else if ((SP) == 2)                                     \
+      KH_L5C(Q, UU, MV, 2, __VA_ARGS__);                    \
+    else                                                    \
+      KH_L5C(Q, UU, MV, 1, __VA_ARGS__);                    \
+  } while (0)
+#define KH_SEL_MV5C(KERNEL_UNUSED, Q, UU, MV, SP, ...)      \
+  do {                                                      \
+    if ((MV) == 2)                                          \
+      KH_SEL_SP5C(Q, UU, 2, SP, __VA_ARGS__);               \
+    else                                                    \
+      KH_SEL_SP5C(Q, UU, 4, SP, __VA_ARGS__);               \
+  } while (0)
 void launch_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
-  const KhGemvResArgs a = fill_wo(m, l);
   const bool qn = c.is_quant;
   const int kh_launch_wg = m->sh_wo.wg;
+  if (m->step_var == 1) {
+    KhWoCombArgs a;
+    a.g = fill_wo(m, l);
+    const AttnSplitWs ws = attn_ws_carve(m->attn_ws, c.head_num, c.head_size, m->attn_ws_stride);
+    a.cb.ml = ws.ml;
+    a.cb.o = ws.o;
+    a.cb.d_pos = m->d_pos;
+    a.cb.ns = m->attn_ns;
+    a.cb.nsw = m->attn_ws_stride;
+    a.cb.heads = c.head_num;
+    a.cb.hs = c.head_size;
+    const int mv = c.dim <= 2 * 4 * kh_launch_wg ? 2 : 4;
+    KH_SEL_U(KH_SEL_MV5C, k_wo_comb, qn, m->sh_wo.u, mv, m->sh_wo.split, m->sh_wo.grid,
+             comb_lds_bytes(qn, c.dim, c.head_num), m->stream, a);
+    return;
+  }
+  const KhGemvResArgs a = fill_wo(m, l);
   KH_DISPATCH4(k_gemv_res, qn, m->sh_wo.u, kh_stage_maxv(c.dim, kh_launch_wg), m->sh_wo.split, m->sh_wo.grid,
                fused_lds_bytes(qn, c.dim), m->stream, a);
 }
@@ -316,8 +352,21 @@ void launch_sample(kh_model* m, int advance, int n_forced) {
   hipLaunchKernelGGL(k_sample, dim3(1), dim3(KH_WG), 0, m->stream, a);
 }
 
+// Which attention / wo pair the steps at positions pos_lo .. pos_hi launch (host decision, per captured
+// graph or eager step).  Variant 1 (time splits merged by k_wo_comb) wherever the per-head path has more
+// than one split to merge; variant 0 (the attention launch leaves the final vector) below position 256,
+// where there is nothing to merge and wo keeps its plain staging, and from the first position of the GQA
+// group path on, whose 32 splits per KV group are merged by their last arriver.
+int step_variant(const kh_model* m, int pos_lo, int pos_hi) {
+  if (!m->attn_defer) return 0;
+  if (pos_hi < KH_ATTN_MIN_TS) return 0;         // pos + 1 <= 256 everywhere: one split
+  if (pos_hi + 1 >= m->attn_t_long) return 0;    // some step runs the group path
+  (void)pos_lo;
+  return 1;
+}
 // one fused decode step = 5L + 2 launches.  ev (optional) receives an event after each launch.
-void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev) {
+void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev, int variant) {
+  m->step_var = variant;
   int e = 0;
   auto mark = [&]() {
     if (ev) (void)hipEventRecord(ev[e++], m->stream);
@@ -416,29 +465,33 @@ int ensure_seq_cap(kh_model* m, int n) {
   KH_CHECK_HIP(hipMemsetAsync(m->d_forced, 0xFF, sizeof(int32_t) * ((size_t)n + 1), m->stream));
   m->seq_cap = n;
   // the graph captured pointers/capacity: rebuild
-  if (m->gexec) (void)hipGraphExecDestroy(m->gexec);
-  if (m->gexecN) (void)hipGraphExecDestroy(m->gexecN);
-  if (m->graph) (void)hipGraphDestroy(m->graph);
-  if (m->graphN) (void)hipGraphDestroy(m->graphN);
-  m->gexec = m->gexecN = nullptr;
-  m->graph = m->graphN = nullptr;
+  destroy_step_graphs(m);
   return KH_OK;
 }
+void destroy_step_graphs(kh_model* m) {
+  for (auto* set : {m->sg1, m->sgN})
+    for (int v = 0; v < 2; ++v) {
+      if (set[v].e) (void)hipGraphExecDestroy(set[v].e);
+      if (set[v].g) (void)hipGraphDestroy(set[v].g);
+      set[v] = kh_model::StepGraph{};
+    }
+}
 
-int capture_steps(kh_model* m, int n_forced, int steps, hipGraph_t* g, hipGraphExec_t* ge) {
+int capture_steps(kh_model* m, int n_forced, int steps, int variant, hipGraph_t* g, hipGraphExec_t* ge) {
   KH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-  for (int i = 0; i < steps; ++i) launch_step_fused(m, /*advance=*/1, n_forced, nullptr);
+  for (int i = 0; i < steps; ++i) launch_step_fused(m, /*advance=*/1, n_forced, nullptr, variant);
   hipError_t e = hipStreamEndCapture(m->stream, g);
   if (e != hipSuccess) return (int)e;
   KH_CHECK_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
   return KH_OK;
 }
-int ensure_graph(kh_model* m, int n_forced) {
-  int rc;
-  if (!m->gexec && (rc = capture_steps(m, n_forced, 1, &m->graph, &m->gexec)) != KH_OK) return rc;
-  if (!m->gexecN &&
-      (rc = capture_steps(m, n_forced, KH_GRAPH_STEPS, &m->graphN, &m->gexecN)) != KH_OK)
-    return rc;
+int step_graph(kh_model* m, int n_forced, int variant, bool steps8, hipGraphExec_t* out) {
+  kh_model::StepGraph& sg = (steps8 ? m->sgN : m->sg1)[variant ? 1 : 0];
+  if (!sg.e) {
+    const int rc = capture_steps(m, n_forced, steps8 ? KH_GRAPH_STEPS : 1, variant ? 1 : 0, &sg.g, &sg.e);
+    if (rc != KH_OK) return rc;
+  }
+  *out = sg.e;
   return KH_OK;
 }
 
@@ -505,7 +558,7 @@ extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t
   if (exec == KH_EXEC_UNFUSED) {
     rc = launch_step_unfused(m, pos);
   } else if (exec == KH_EXEC_FUSED || exec == KH_EXEC_GRAPH) {
-    launch_step_fused(m, /*advance=*/0, /*n_forced=*/0, nullptr);
+    launch_step_fused(m, /*advance=*/0, /*n_forced=*/0, nullptr, step_variant(m, pos, pos));
     rc = kh_launch_status();
   } else {
     return KH_ERR_INVALID_ARG;
@@ -579,7 +632,6 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
                               hipMemcpyHostToDevice, m->stream));
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));  // `forced` is a stack-lifetime staging buffer
   const int n_forced = m->seq_cap + 1;
-  if (exec == KH_EXEC_GRAPH && (rc = ensure_graph(m, n_forced)) != KH_OK) return rc;
 
   // prompt phase: the tokens that are only fed (positions 0 .. n_prompt-2).  KH_PREFILL selects how:
   //   "0" / "token"  the reference's one forward pass per prompt token (demo/main.cpp:20-22)
@@ -591,7 +643,7 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   int start = 0;
   KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
   if (n_prompt - 1 >= 2 && n_prompt - 1 < total_steps) {
-    const char* e = getenv("KH_PREFILL");
+    const char* e = dbg("KH_PREFILL");
     bool want_gemm = n_prompt - 1 >= KH_PG_MIN_TOKENS, want_gemv = true;
     if (e && *e) {
       if (!strcmp(e, "0") || !strcmp(e, "token")) want_gemm = want_gemv = false;
@@ -608,16 +660,16 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     }
   }
   set_state(m, h_prompt[start], start);
-  auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps
+  auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps (positions s ..)
     if (exec == KH_EXEC_GRAPH) {
-      if (total_steps - s >= KH_GRAPH_STEPS) {
-        if (hipGraphLaunch(m->gexecN, m->stream) != hipSuccess) return -1;
-        return KH_GRAPH_STEPS;
-      }
-      if (hipGraphLaunch(m->gexec, m->stream) != hipSuccess) return -1;
-      return 1;
+      const bool n8 = total_steps - s >= KH_GRAPH_STEPS;
+      const int n = n8 ? KH_GRAPH_STEPS : 1;
+      hipGraphExec_t ge = nullptr;
+      if (step_graph(m, n_forced, step_variant(m, s, s + n - 1), n8, &ge) != KH_OK) return -1;
+      if (hipGraphLaunch(ge, m->stream) != hipSuccess) return -1;
+      return n;
     }
-    launch_step_fused(m, 1, n_forced, nullptr);
+    launch_step_fused(m, 1, n_forced, nullptr, step_variant(m, s, s));
     return 1;
   };
   int n_out = total_steps;

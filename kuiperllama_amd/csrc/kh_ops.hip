@@ -489,6 +489,7 @@ static int launch_mha_fast(const int32_t* d_pos, int32_t pos, int32_t head_num,
   a.ws_stride = ws_stride;
   a.nsplit_g = nsplit_g;
   a.t_long = t_long;
+  a.defer = 0;  // operator level: the launch leaves the final output
   a.tok_stride = 0;
   a.ws_tok_bytes = 0;
   launch_attn_decode(a, pos, KH_WG_MAX, s);
@@ -518,23 +519,13 @@ extern "C" int kh_mha_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
 }
 
 // Decode attention with the long-context time split (the kernel the fused step launches).
-// Split geometry of the decode launch for a cache of seq_len rows (mirrors kh_model_load.hip::finish_create).
 static void mha_decode_geometry(int head_num, int kv_mul, int head_size, int seq_len, int* ns,
                                 int* ns_g, int* stride, int* t_long) {
-  *ns = head_size > 32 ? attn_num_splits(seq_len) : 1;
-  *ns_g = 0;
-  *stride = *ns;
-  *t_long = 1 << 30;
-  if (kv_mul > 1 && head_size > 32 && head_num % kv_mul == 0 &&
-      attn_group_supported(head_size, kv_mul, KH_WG_MAX)) {
-    int tl = head_num / kv_mul >= KH_ATTN_MIN_GROUPS ? KH_ATTN_TLONG_DEFAULT : 0;
-    if (const char* e = getenv("KH_ATTN_TLONG")) tl = atoi(e);
-    if (tl > 0 && tl <= seq_len) {
-      *ns_g = attn_group_splits(seq_len, head_num / kv_mul);
-      *t_long = tl;
-      if (*ns_g > *stride) *stride = *ns_g;
-    }
-  }
+  const AttnPlan p = attn_plan(head_num, kv_mul, head_size, seq_len, KH_WG_MAX, attn_tlong_hook());
+  *ns = p.ns;
+  *ns_g = p.ns_g;
+  *stride = p.stride;
+  *t_long = p.t_long;
 }
 static int64_t mha_decode_workspace_bytes_for(int32_t head_num, int32_t kv_mul, int32_t head_size,
                                               int32_t seq_len) {

@@ -240,7 +240,7 @@ static inline bool pg_attn_supported(int head_size) {
 // workgroups.  Head size 128 stops at 2 (registers).  KH_PG_ATTN_QT forces a value.
 static inline int pg_attn_qt(const KhPgAttnArgs& a, int head_size) {
   const int heads = a.kv_heads * a.kv_mul, maxqt = head_size == 128 ? 2 : 4;
-  const char* e = getenv("KH_PG_ATTN_QT");  // (per launch: the tests switch it)
+  const char* e = khm::dbg("KH_PG_ATTN_QT");
   const int forced = e ? atoi(e) : 0;
   if (forced == 1 || forced == 2 || forced == 4) return forced < maxqt ? forced : maxqt;
   if (a.pos0 < 2048) return 1;

@@ -37,6 +37,7 @@ class KuiperModel:
     @classmethod
     def from_file(cls, path: str, spec: binfmt.ModelSpec, max_seq_len: int = 0,
                   device: int = 0, flags: int = 0) -> "KuiperModel":
+        _ffi.sync_env()
         h = C.c_void_p()
         o = _opts(spec, max_seq_len, device, flags)
         _ffi.check(_ffi.lib().kh_model_create_from_file(path.encode(), C.byref(o), C.byref(h)),
@@ -47,6 +48,7 @@ class KuiperModel:
     def from_host_image(cls, image: np.ndarray, spec: binfmt.ModelSpec, max_seq_len: int = 0,
                         device: int = 0, flags: int = 0) -> "KuiperModel":
         assert image.dtype == np.uint8 and image.flags["C_CONTIGUOUS"]
+        _ffi.sync_env()
         h = C.c_void_p()
         o = _opts(spec, max_seq_len, device, flags)
         _ffi.check(_ffi.lib().kh_model_create_from_host_image(image.ctypes.data, image.size,
@@ -75,6 +77,7 @@ class KuiperModel:
             weights.copy_(image[hb:])
             keep = weights
         torch.cuda.synchronize()
+        _ffi.sync_env()
         h = C.c_void_p()
         o = _opts(spec, max_seq_len, device, flags)
         hdr = (C.c_int32 * 8)(*header.tolist()[:8])
@@ -143,6 +146,7 @@ class KuiperModel:
         """Returns (words, elapsed_ms of the step loop measured with HIP events).  `stop` = the
         reference's sentence-ending token ids (demo/main.cpp:30-32); the stop token itself is not
         part of `words`."""
+        _ffi.sync_env()  # KH_PREFILL, KH_PG_*
         pr = (C.c_int32 * len(prompt))(*[int(t) for t in prompt])
         st = list(stop or [])
         sp = (C.c_int32 * max(len(st), 1))(*[int(t) for t in st])
@@ -166,6 +170,7 @@ class KuiperModel:
     def prefill_gemm(self, tokens: Sequence[int], pos0: int = 0) -> None:
         """Forward of `tokens` at positions pos0.. as fp32-MFMA GEMMs (up to 128 tokens per weight
         pass); K/V rows equal the token-by-token ones to fp32 round-off."""
+        _ffi.sync_env()
         t = (C.c_int32 * len(tokens))(*[int(x) for x in tokens])
         _ffi.check(_ffi.lib().kh_model_prefill_gemm(self._h, t, len(tokens), pos0),
                    "kh_model_prefill_gemm")
@@ -177,6 +182,7 @@ class KuiperModel:
         """Milliseconds (HIP events on the model stream) of the prompt phase alone for `tokens`:
         "token" = one forward pass per token (the reference), "gemv" = B-token VALU kernels,
         "gemm" = fp32-MFMA GEMM prefill."""
+        _ffi.sync_env()
         t = (C.c_int32 * len(tokens))(*[int(x) for x in tokens])
         ms = C.c_float(0.0)
         _ffi.check(_ffi.lib().kh_model_time_prefill(self._h, t, len(tokens), pos0,

@@ -117,6 +117,7 @@ def mha(pos, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size, mha_out,
 def mha_prefill(pos0, n_tokens, head_num, layer_index, seq_len, kv_dim, kv_mul, head_size, mha_out, q,
                 kcache, vcache):
     """Causal attention of n_tokens consecutive queries (rows of q) on the matrix cores."""
+    _ffi.sync_env()  # KH_PG_ATTN_QT
     _ffi.check(_ffi.lib().kh_mha_prefill_f32(
         int(pos0), int(n_tokens), head_num, layer_index, seq_len, kv_dim, kv_mul, head_size,
         _p(mha_out, torch.float32), _p(q, torch.float32), _p(kcache, torch.float32),
@@ -126,6 +127,7 @@ def mha_prefill(pos0, n_tokens, head_num, layer_index, seq_len, kv_dim, kv_mul, 
 
 def mha_decode_workspace(head_num: int, head_size: int, seq_len: int, device):
     """Zeroed workspace tensor for mha_decode (None when no time split is needed)."""
+    _ffi.sync_env()  # KH_ATTN_TLONG
     n = int(_ffi.lib().kh_mha_decode_workspace_bytes(head_num, head_size, seq_len))
     if n < 0:
         _ffi.check(n, "kh_mha_decode_workspace_bytes")

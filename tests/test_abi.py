@@ -67,3 +67,32 @@ def test_ops_refuse_cpu_tensors():
     a = torch.zeros(4)
     with pytest.raises(ValueError):
         ops.add(a, a, a)
+
+
+def test_debug_hooks_live_in_one_table_not_in_getenv(lib, monkeypatch):
+    """Tuning / test hooks: set, read back, listed, cleared through kh_debug_*; the launch-plan entry
+    points honour a hook set through the API; no translation unit of the library calls getenv."""
+    assert lib.kh_debug_set(b"NOT_A_HOOK", b"1") == -1
+    assert _ffi.debug_get("KH_TEST_HOOK") is None
+    _ffi.debug_set("KH_TEST_HOOK", "abc")
+    assert _ffi.debug_get("KH_TEST_HOOK") == "abc"
+    n = lib.kh_debug_list(None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.kh_debug_list(buf, n)
+    assert "KH_TEST_HOOK" in buf.value.decode().split("\n")
+    _ffi.debug_set("KH_TEST_HOOK", None)
+    assert _ffi.debug_get("KH_TEST_HOOK") is None
+    # a shape hook set through the API changes the plan; sync_env() mirrors os.environ (here: clears it)
+    base = _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"]
+    _ffi.debug_set("KH_SHAPE_FFN", "1,4,256,256")
+    out = (C.c_int32 * 20)()
+    assert lib.kh_plan_decode_shapes(2048, 8192, 512, 128256, 0, out) == 0
+    assert list(out[8:12]) == [1, 4, 256, 256]
+    assert _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"] == base  # env has no such hook
+    monkeypatch.setenv("KH_SHAPE_FFN", "1,4,512,256")
+    assert _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"]["grid"] == 512
+    monkeypatch.delenv("KH_SHAPE_FFN")
+    _ffi.sync_env()
+    csrc = os.path.join(ROOT, "kuiperllama_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f

@@ -199,6 +199,80 @@ def test_long_generate_crosses_attention_splits(gpu, oracle):
     m2.close()
 
 
+_DEFER_SPECS = {
+    # Llama-3.2-1B heads (32 x 64, 8 KV heads) on 2 layers; cache 4096 -> 16 splits, group path at 4095
+    "gqa-1b-heads": binfmt.ModelSpec(2048, 2048, 2, 32, 8, 1024, 4096, True, binfmt.FAMILY_LLAMA, False, 64,
+                                     binfmt.ROPE_HALF, 500000.0, 1e-5, "defer-gqa"),
+    # Qwen2.5-0.5B heads (14 x 64, 2 KV heads: no group path), bias
+    "qwen-heads": binfmt.ModelSpec(896, 1216, 2, 14, 2, 700, 4096, True, binfmt.FAMILY_QWEN2, False, 64,
+                                   binfmt.ROPE_HALF, 1000000.0, 1e-6, "defer-qwen"),
+    # Llama-2-7B heads (head size 128, MHA) int8, cache 2048 -> 8 splits; dim 4096 takes the 4-float4 staging
+    "mha-hs128-int8": binfmt.ModelSpec(4096, 1024, 2, 32, 32, 512, 2048, False, binfmt.FAMILY_LLAMA, True, 64,
+                                       binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "defer-mha-int8"),
+    # the same fp32: the 64-register weight tile (U = 8) stages the vector before its first tile
+    "mha-hs128-f32": binfmt.ModelSpec(4096, 1024, 2, 32, 32, 512, 2048, False, binfmt.FAMILY_LLAMA, False, 64,
+                                      binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "defer-mha-f32"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_DEFER_SPECS))
+def test_deferred_split_merge_equals_in_launch_merge(gpu, oracle, name):
+    """Positions that need several attention time splits: by default the split workgroups leave their
+    (M, L, o) partials and the wo kernel merges them while it stages its input (k_wo_comb, step variant 1);
+    KH_FLAG_ATTN_MERGE_IN_LAUNCH keeps the ticket + last-arriver merge inside the attention launch.  Both run
+    the same fmaf chains in the same order: logits must be IDENTICAL, at split counts 1 (pos 255: no
+    merge, plain wo) 2, 3, 4, ... 16 / 8 and across the hand-over to the GQA group path, eager and under
+    graph replay; and both sit within the fp32 tolerance of the oracle."""
+    from kuiperllama_amd import _ffi
+    from kuiperllama_amd.model import KuiperModel
+    spec = _DEFER_SPECS[name]
+    img_d, img_h = _synth(spec, 77, gpu, wander=True)
+    m = KuiperModel.from_device_image(img_d, spec)
+    mi = KuiperModel.from_device_image(img_d, spec, flags=_ffi.KH_FLAG_ATTN_MERGE_IN_LAUNCH)
+    om = oracle.OracleModel.from_spec(img_h, spec)
+    ko, vo = om.kv_cache()
+    rng = np.random.default_rng(11)
+    top = spec.seq_len
+    for l in range(spec.n_layers):
+        kr = rng.standard_normal((top, spec.kv_dim), dtype=np.float32)
+        vr = rng.standard_normal((top, spec.kv_dim), dtype=np.float32)
+        kr[rng.integers(0, top, 8)] *= 6.0  # a few dominant keys: the splits' maxima differ
+        ko[l, :top] = kr
+        vo[l, :top] = vr
+        m.write_kv(l, 0, kr, vr)
+        mi.write_kv(l, 0, kr, vr)
+    poss = [255, 256, 300, 511, 512, 767, 1000, 1535, 2046, 2047]
+    if top > 2048:
+        poss += [3000, 4093, 4094, 4095]
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, len(poss))]
+    atol = 1e-4 if spec.quant else 4e-5
+    for tok, pos in zip(toks, poss):
+        a = m.predict(tok, pos, exec="fused")
+        la = m.logits()
+        b = mi.predict(tok, pos, exec="fused")
+        lb = mi.logits()
+        assert np.array_equal(la, lb), f"pos {pos}: deferred vs in-launch merge differ by {np.abs(la - lb).max():.3e}"
+        assert a == b
+        if pos in (256, 1000, 2047, 4094):
+            lo = om.forward(tok, pos)
+            assert np.abs(la - lo).max() <= atol, f"pos {pos}: |logit - oracle| {np.abs(la - lo).max():.3e}"
+    # graph replay: 24 steps from position 250 cross 256 inside an 8-step graph (variant hand-over)
+    for mm in (m, mi):
+        for l in range(spec.n_layers):
+            mm.write_kv(l, 0, ko[l, :300], vo[l, :300])
+    prompt = [int(t) for t in rng.integers(0, spec.vocab_size, 251)]
+    os.environ["KH_PREFILL"] = "gemv"  # the bit-identical prompt path for both
+    try:
+        ga, _ = m.generate(prompt, 251 + 24, exec="graph")
+        gb, _ = mi.generate(prompt, 251 + 24, exec="graph")
+        gc, _ = m.generate(prompt, 251 + 24, exec="fused")
+    finally:
+        del os.environ["KH_PREFILL"]
+    assert ga == gb == gc
+    m.close()
+    mi.close()
+
+
 def test_loader_entry_points_agree(gpu):
     from kuiperllama_amd.model import KuiperModel
     spec, img, toks, ref = load_golden("ref_llama_mha_untied")
