@@ -49,6 +49,8 @@ sys.path.insert(0, ROOT)
 from kuiperllama_amd import binfmt  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# logits vs the oracle at one greedy step (tests/test_model_gpu.py holds the same bounds at full size)
+LOGIT_TOL_F32, LOGIT_TOL_Q8, LOGIT_CHECK_POS = 4e-5, 1e-4, 8
 PROMPT = [1, 263]  # BOS + "a": the demo prompt (demo/main.cpp:64) under the Llama-2 vocab
 
 
@@ -90,7 +92,7 @@ def timed_generate(m, steps, warmup, world, dev):
     return res["words"], wall, res["ev_ms"]
 
 
-def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=10.0):
+def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=10.0, gpu_logits=None):
     """Oracle (port of the reference CPU backend) on this host's cores, bounded sample.  Two
     matmul variants: (i) the oracle's own OpenMP row-parallel GEMV, (ii) the oracle
     with its fp32 matmuls routed through numpy's bundled OpenBLAS sgemv (the reference's
@@ -139,11 +141,18 @@ def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=1
     n = 0
     first_words = None
     passes = 0
+    logit_check = None
     while True:
         words = []
         for pos in range(max_tokens):
             tok = seq[pos] if pos < len(PROMPT) else words[pos - 1]
             lg = om.forward(int(tok), pos)
+            if gpu_logits is not None and logit_check is None and pos == gpu_logits[0]:
+                # SURVEY 8(c) stated tolerance, checked in the record itself: the GPU's logits of the same
+                # greedy step (same prompt, same fed tokens while the words agree) against the oracle's
+                tol = LOGIT_TOL_Q8 if spec.quant else LOGIT_TOL_F32
+                err = float(np.abs(lg - gpu_logits[1]).max())
+                logit_check = {"pos": pos, "max_abs_err": err, "tolerance": tol, "ok": bool(err <= tol)}
             nxt = PROMPT[pos + 1] if pos < len(PROMPT) - 1 else int(np.argmax(lg))
             words.append(nxt)
             n += 1
@@ -170,7 +179,8 @@ def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=1
             "sample": f"{n} decode steps = {passes} pass(es) over the first {len(words)} steps of the "
                       f"same greedy decode ({spec.name}, prompt {PROMPT}), {how}, {dt:.1f}s",
             "variant": variant, "calibration_ms_per_token": calib,
-            "tokens_match_gpu": bool(match), "tokens_compared": n_cmp, "first_divergence": div}
+            "tokens_match_gpu": bool(match), "tokens_compared": n_cmp, "first_divergence": div,
+            "max_logit_err_vs_oracle": logit_check}
 
 
 def host_cpu_facts() -> dict:
@@ -236,7 +246,7 @@ def host_mem_available_gb() -> float:
     return avail
 
 
-def cpu_int8_restated(spec_q8, img_q8_dev, args):
+def cpu_int8_restated(spec_q8, img_q8_dev, args, gpu_words, gpu_logits):
     """the reference has NO CPU int8 path (kernels_interfaces.cpp:54-61), so
     the CPU comparison points for Llama-2-7B int8 are (i) CPU fp32 Llama-2-7B - measured with the
     fp32 image under other_configs.llama2-7b.cpu_baseline - and (ii) the oracle's own restated CPU
@@ -245,10 +255,11 @@ def cpu_int8_restated(spec_q8, img_q8_dev, args):
     third = max(4.0, args.cpu_budget_s / 3)
     img_h = img_q8_dev.cpu().numpy()
     try:
-        r = cpu_baseline(spec_q8, img_h, [], 16, third, min_sample_s=third)
+        r = cpu_baseline(spec_q8, img_h, gpu_words, 16, third, min_sample_s=third, gpu_logits=gpu_logits)
     finally:
         del img_h
-    out = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant", "host")}
+    out = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant", "host", "tokens_match_gpu",
+                             "tokens_compared", "first_divergence", "max_logit_err_vs_oracle")}
     out["label"] = ("oracle restatement of cuda/matmul_kernel.cu:56-87 on the host; the reference itself "
                     "has no CPU int8")
     return {"cpu_int8_restated": out,
@@ -323,14 +334,59 @@ def long_context(m, spec, dev):
             m.write_kv_device(l, r0, kv[0], kv[1])
     torch.cuda.synchronize(dev)
     out = {}
+    wo_short = m.profile_kernel("wo", 64, reps=4)  # wo with a plain input vector (nothing to merge)
     for p in poss:
         us = sorted(m.time_step(p, 9))
         attn_us = m.profile_kernel("attn", p, reps=4)
+        wo_us = m.profile_kernel("wo", p, reps=4)
+        # between position 256 and the GQA group path the split partials are merged by the wo kernel
+        # (k_wo_comb): what that adds to wo is attention time and is charged to it here
+        merge_us = max(0.0, wo_us - wo_short)
         kv_bytes = 2.0 * (p + 1) * spec.kv_dim * 4
-        out[str(p)] = {"step_us": round(us[len(us) // 2], 2), "attn_us_per_layer": round(attn_us, 2),
+        out[str(p)] = {"step_us": round(us[len(us) // 2], 2), "attn_us_per_layer": round(attn_us + merge_us, 2),
+                       "attn_kernel_us": round(attn_us, 2), "wo_us": round(wo_us, 2),
+                       "wo_us_plain_input": round(wo_short, 2),
                        "attn_kv_bytes_per_layer": kv_bytes,
-                       "attn_kv_frac": kv_bytes / (attn_us * 1e-6) / (HBM_PEAK_GBS * 1e9)}
+                       "attn_kv_frac": kv_bytes / ((attn_us + merge_us) * 1e-6) / (HBM_PEAK_GBS * 1e9)}
     return out
+
+
+def load_probe(spec, img_dev, device_index, gpu_words):
+    """SURVEY 8(f1): Model::read_model_file + to_cuda (model.cpp:41-123) timed on a real file - the .bin
+    image the GPU just decoded from, written to /dev/shm (page-cache resident, as a second load of a
+    checkpoint is), loaded with kh_model_create_from_file (mmap -> double-buffered pinned chunks -> one
+    HBM arena), then 8 greedy steps as a sanity check against the words of the timed run."""
+    from kuiperllama_amd.model import KuiperModel
+    nbytes = int(img_dev.numel())
+    st = os.statvfs("/dev/shm")
+    if st.f_bavail * st.f_frsize < nbytes + (1 << 30) or host_mem_available_gb() < 2 * nbytes / 1e9 + 4:
+        return {"skipped": "not enough /dev/shm or host memory for the image"}
+    path = f"/dev/shm/kh_bench_{os.getpid()}.bin"
+    try:
+        img_dev.cpu().numpy().tofile(path)
+        t0 = time.perf_counter()
+        m = KuiperModel.from_file(path, spec, device=device_index)
+        wall = time.perf_counter() - t0
+        up_ms = m.load_ms
+        words, _ = m.generate(PROMPT, 8, exec="graph")
+        m.close()
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    return {"bytes": nbytes, "ms": round(wall * 1e3, 1), "GB/s": round(nbytes / wall / 1e9, 2),
+            "upload_ms": round(up_ms, 1), "upload_GB/s": round(nbytes / (up_ms * 1e-3) / 1e9, 2) if up_ms else None,
+            "what": "kh_model_create_from_file on the .bin image in /dev/shm: `ms` = the whole call (open, mmap, "
+                    "header, chunked pinned upload, buffers, sin/cos table, launch plans), `upload_ms` = the weight "
+                    "upload alone (kh_model_get_load_ms)",
+            "decode_matches_timed_run": words == list(gpu_words[:8])}
+
+
+_T0 = time.time()
+
+
+def time_left(args) -> float:
+    """Seconds left of the wall-clock budget of the optional sections (the contract line must be printed)."""
+    return args.budget_s - (time.time() - _T0)
 
 
 def measure(spec, args, rank, world, local_rank, primary):
@@ -435,31 +491,43 @@ def measure(spec, args, rank, world, local_rank, primary):
     if args.extras:
         prof = m.profile_step(start_pos=ppos, n_steps=8)
         out["roofline"]["kernels_avg_us_evented"] = {n: round(v["avg_us"], 3) for n, v in prof.items()}
-        if primary and world == 1:
+        if primary and world == 1 and time_left(args) > 60:
             try:
                 lc = long_context(m, spec, dev)
                 if lc:
                     out["long_context"] = lc
             except Exception as e:  # noqa: BLE001  (the contract's numbers must still be reported)
                 out["long_context"] = {"error": repr(e)}
+    gpu_logits = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.extras:
+        # logits of greedy step LOGIT_CHECK_POS of the same prompt, for the record's own tolerance check
+        m.generate(PROMPT, LOGIT_CHECK_POS + 1, exec="graph")
+        gpu_logits = (LOGIT_CHECK_POS, m.logits())
     m.close()
     del m
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.extras:
         if primary:
             img_h = img.cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(spec, img_h, ref_words, args.cpu_tokens, args.cpu_budget_s)
+            out["cpu_baseline"] = cpu_baseline(spec, img_h, ref_words, args.cpu_tokens, args.cpu_budget_s,
+                                               gpu_logits=gpu_logits)
             del img_h
         elif spec.name == "llama2-7b-int8":
             try:
-                out["cpu_baseline"] = cpu_int8_restated(spec, img, args)
+                out["cpu_baseline"] = cpu_int8_restated(spec, img, args, ref_words, gpu_logits)
+                out["max_logit_err_vs_oracle"] = out["cpu_baseline"]["cpu_int8_restated"]["max_logit_err_vs_oracle"]
             except Exception as e:  # noqa: BLE001  (the GPU numbers must still be reported)
                 out["cpu_baseline"] = {"error": repr(e)}
+    if primary and rank == 0 and world == 1 and args.extras and time_left(args) > 30:
+        try:
+            out["load"] = load_probe(spec, img, local_rank, words)
+        except Exception as e:  # noqa: BLE001
+            out["load"] = {"error": repr(e)}
     del img
     torch.cuda.empty_cache()
     return out
 
 
-DEFAULT_OTHERS = "qwen2.5-0.5b,tinyllama-1.1b,llama2-7b"
+DEFAULT_OTHERS = "stories15M,qwen2.5-0.5b,tinyllama-1.1b,llama2-7b"
 NORTH_STAR_FLOOR = {"config": "tinyllama-1.1b", "target_tok_s": 60.0,
                     "source": "north_star: >= the reference's 60 tok/s on TinyLlama-1.1B fp32 "
                               "(/root/reference/readme.md:25: 60.34 tok/s, RTX 3060 Laptop)"}
@@ -490,6 +558,10 @@ def main(argv=None):
     ap.add_argument("--others", default=None,
                     help=f"comma-separated further BASELINE configs measured briefly into the same line "
                          f"(default on one GPU: {DEFAULT_OTHERS}; '' or --no-others: none)")
+    ap.add_argument("--budget-s", type=float, default=420.0,
+                    help="wall-clock budget of the whole command: optional sections (long context, load probe, "
+                         "other configs) that would start after it are skipped and named in `skipped_sections`, "
+                         "so the contract line is always printed")
     ap.add_argument("--no-others", action="store_true",
                     help="skip the other BASELINE configs (rocprofv3 runs: they launch the same kernel "
                          "instantiations at other sizes and would blur the --stats average)")
@@ -516,6 +588,7 @@ def main(argv=None):
         args.others = ""
 
     spec = binfmt.PRESETS[args.workload]
+    skipped = []
     res = measure(spec, args, rank, world, local_rank, primary=True)
     secondary = None
     if args.secondary and args.secondary != args.workload:
@@ -532,6 +605,8 @@ def main(argv=None):
                          "prefill": r2.get("prefill")}
             if "cpu_baseline" in r2:
                 secondary["cpu_baseline"] = r2["cpu_baseline"]
+            if "max_logit_err_vs_oracle" in r2:
+                secondary["max_logit_err_vs_oracle"] = r2["max_logit_err_vs_oracle"]
         except Exception as e:  # the primary number must still be reported
             secondary = {"error": repr(e)}
 
@@ -540,6 +615,10 @@ def main(argv=None):
         others = {}
         torch.cuda.empty_cache()
         for w in [x for x in args.others.split(",") if x and x not in (args.workload, args.secondary)]:
+            # the 26 GB fp32 image needs ~90 s (synthesis, 3 x 128 steps, host copy, CPU pass); the rest ~10 s
+            if time_left(args) < (100 if binfmt.image_nbytes(binfmt.PRESETS[w]) > 8e9 else 15):
+                skipped.append(f"other_configs.{w}")
+                continue
             try:
                 others[w] = other_config(binfmt.PRESETS[w], local_rank, args)
             except Exception as e:  # noqa: BLE001 - the contract's numbers must still be reported
@@ -570,6 +649,10 @@ def main(argv=None):
         }
         if "long_context" in res:
             line["long_context"] = res["long_context"]
+        if "load" in res:
+            line["load"] = res["load"]
+        if skipped:
+            line["skipped_sections"] = skipped
         if "cpu_baseline" in res:
             line["cpu_baseline"] = res["cpu_baseline"]
         if secondary is not None:

@@ -146,5 +146,5 @@ def test_bench_flags_can_be_switched_off():
     spec.loader.exec_module(bm)
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "BooleanOptionalAction" in src and "--no-others" in src
-    assert bm.DEFAULT_OTHERS.split(",") == ["qwen2.5-0.5b", "tinyllama-1.1b", "llama2-7b"]
+    assert bm.DEFAULT_OTHERS.split(",") == ["stories15M", "qwen2.5-0.5b", "tinyllama-1.1b", "llama2-7b"]
     assert bm.NORTH_STAR_FLOOR["config"] == "tinyllama-1.1b" and bm.NORTH_STAR_FLOOR["target_tok_s"] == 60.0
