@@ -53,6 +53,7 @@ struct kh_model {
   int attn_t_long = 1 << 30;
   int attn_wg = KH_WG;
   bool attn_defer = false;  // variant 1 exists: split partials combined by kh_fused.h::k_wo_comb
+  int attn_defer_max = 0;   // ... up to this many active splits (more: the in-launch merge is as fast or faster)
   int step_var = 0;         // variant the launch_* helpers use right now (set by launch_step_fused / profile)
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;

@@ -268,6 +268,13 @@ int finish_create(kh_model* m) {
   // needs wo's in-register staging (dim <= 16 floats per thread) and heads * 16 factor slots per pass
   m->attn_defer = m->attn_ns > 1 && !(m->opts.flags & KH_FLAG_ATTN_MERGE_IN_LAUNCH) && !dbg_off("KH_ATTN_DEFER") &&
                   comb_supported(c.dim, c.head_num, c.head_size, m->sh_wo.wg);
+  {
+    // mirrors k_wo_comb's OVERLAP (kh_fused.h): does the combine travel beside wo's first weight tile?
+    const int mv = c.dim <= 2 * 4 * m->sh_wo.wg ? 2 : 4;
+    const bool overlap = !(m->sh_wo.u >= 8 || (c.is_quant && m->sh_wo.u >= 4 && mv >= 4));
+    m->attn_defer_max = overlap ? KH_ATTN_MAX_NS : 4;
+    if (const char* e = dbg("KH_ATTN_DEFER_MAX")) m->attn_defer_max = atoi(e);
+  }
   if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride)) {
     KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
     KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));

@@ -356,11 +356,15 @@ void launch_sample(kh_model* m, int advance, int n_forced) {
 // graph or eager step).  Variant 1 (time splits merged by k_wo_comb) wherever the per-head path has more
 // than one split to merge; variant 0 (the attention launch leaves the final vector) below position 256,
 // where there is nothing to merge and wo keeps its plain staging, and from the first position of the GQA
-// group path on, whose 32 splits per KV group are merged by their last arriver.
+// group path on, whose 32 splits per KV group are merged by their last arriver.  Every wo workgroup
+// re-reads all nact partials (nact x dim floats from L2: 64 MB over the launch at 16 splits of a 2048-wide
+// model, +3.3 us), so shapes whose staging cannot hide under wo's first weight tile (kh_fused.h:
+// OVERLAP) defer only up to 4 splits (profiles/r4_attn_defer_ab.txt: Llama-2-7B int8 loses from 8 on).
 int step_variant(const kh_model* m, int pos_lo, int pos_hi) {
   if (!m->attn_defer) return 0;
   if (pos_hi < KH_ATTN_MIN_TS) return 0;         // pos + 1 <= 256 everywhere: one split
   if (pos_hi + 1 >= m->attn_t_long) return 0;    // some step runs the group path
+  if (attn_active_splits(pos_hi, m->attn_ns) > m->attn_defer_max) return 0;
   (void)pos_lo;
   return 1;
 }
