@@ -138,3 +138,18 @@ def build_ref_layers() -> str | None:
     subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
                            "ref_layers", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
     return REF_LAYERS_BIN
+
+
+REF_MODEL_BIN = os.path.normpath(os.path.join(_PKG, "..", "oracle", "_ref", "test_ref_model"))
+
+
+def build_ref_model() -> str | None:
+    """tests/cpp/test_ref_model.cpp: the reference's OWN model::LLama2Model (model/{model,llama3,raw_model_data}.cpp,
+    sampler/argmax_sampler.cpp, op/encode.cpp compiled where they lie) over the HIP getters + libkuiper_hip.so
+    (oracle/Makefile `ref_model`).  Only where the reference checkout exists; the binary travels to the GPU box."""
+    if not os.path.isdir(os.path.join(REF_ROOT, "kuiper", "include")):
+        return REF_MODEL_BIN if os.path.exists(REF_MODEL_BIN) else None
+    build_lib()
+    subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
+                           "ref_model", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
+    return REF_MODEL_BIN

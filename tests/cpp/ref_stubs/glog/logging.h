@@ -1,6 +1,7 @@
 // TEST-ONLY stand-in for <glog/logging.h>: just enough for the reference's headers and the host
 // sources behind tensor::Tensor (LOG(severity) << ..., CHECK*(...) << ...).
 #pragma once
+#include <unistd.h>  // the real glog header brings it in; model.cpp:84 calls close() relying on that
 #include <cstdlib>
 #include <iostream>
 #include <sstream>
@@ -36,3 +37,6 @@ constexpr bool kINFO = false, kWARNING = false, kERROR = false, kFATAL = true;
 #define CHECK_LE(a, b) CHECK((a) <= (b))
 #define CHECK_GT(a, b) CHECK((a) > (b))
 #define CHECK_GE(a, b) CHECK((a) >= (b))
+// LOG_IF(severity, condition) << ...   (llama3.cpp:591, demo/main.cpp:9)
+#define LOG_IF(sev, cond) \
+  !(cond) ? (void)0 : refstub::Voidify() & refstub::LogMessage(refstub::k##sev, __FILE__, __LINE__).stream()

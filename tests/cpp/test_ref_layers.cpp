@@ -25,6 +25,7 @@
 
 #include "base/alloc.h"
 #include "kuiper_hip_adapter.hpp"
+#include "kuiper_hip_alloc.hpp"
 #include "op/add.h"
 #include "op/embedding.h"
 #include "op/matmul.h"
@@ -43,7 +44,9 @@
 
 namespace {
 using tensor::Tensor;
-constexpr auto kDev = base::DeviceType::kDeviceCUDA;  // the device tag of the reference's allocator
+constexpr auto kDev = static_cast<base::DeviceType>(3);  // kDeviceHIP: the tag include/kuiper_hip_alloc.hpp stamps
+using HipAllocator = kuiper_hip::HipDeviceAllocator<base::DeviceAllocator, base::DeviceType, base::MemcpyKind, kDev>;
+std::shared_ptr<HipAllocator> hip_alloc() { return kuiper_hip::allocator_instance<HipAllocator>(); }
 constexpr auto kF32 = base::DataType::kDataTypeFp32;
 
 struct Lcg {  // deterministic values in [-1, 1)
@@ -61,11 +64,11 @@ std::vector<float> rnd(size_t n, uint32_t seed, float amp = 1.f) {
   return v;
 }
 Tensor dev_tensor(base::DataType dt, const std::vector<int32_t>& dims) {
-  return Tensor(dt, dims, /*need_alloc=*/true, base::CUDADeviceAllocatorFactory::get_instance());
+  return Tensor(dt, dims, /*need_alloc=*/true, hip_alloc());
 }
 Tensor dev_f32(const std::vector<float>& h, const std::vector<int32_t>& dims) {
   Tensor t = dev_tensor(kF32, dims);
-  (void)hipMemcpy(t.ptr<float>(), h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hip_alloc()->memcpy(h.data(), t.ptr<float>(), h.size() * 4, base::MemcpyKind::kMemcpyCPU2CUDA);
   return t;
 }
 Tensor host_i32(const std::vector<int32_t>& h) {
@@ -76,7 +79,7 @@ Tensor host_i32(const std::vector<int32_t>& h) {
 std::vector<float> to_host(const Tensor& t) {
   std::vector<float> h(t.size());
   (void)hipDeviceSynchronize();
-  (void)hipMemcpy(h.data(), t.ptr<float>(), h.size() * 4, hipMemcpyDeviceToHost);
+  hip_alloc()->memcpy(t.ptr<float>(), h.data(), h.size() * 4, base::MemcpyKind::kMemcpyCUDA2CPU);
   return h;
 }
 // The model holds its operators as std::shared_ptr<op::Layer> (llama3.cpp:24-60) and calls the
@@ -144,8 +147,8 @@ int matmul_layer(std::shared_ptr<kernel::CudaConfig> cfg) {
   for (auto& v : sc2) v = 0.002f + 0.0005f * (r.next() + 1.f);
   auto xq = rnd(Mq, 12);
   Tensor blob = dev_tensor(base::DataType::kDataTypeInt8, {(int32_t)(nq + ns * 4)});
-  (void)hipMemcpy(blob.ptr<int8_t>(), w8.data(), nq, hipMemcpyHostToDevice);
-  (void)hipMemcpy(blob.ptr<int8_t>() + nq, sc.data(), ns * 4, hipMemcpyHostToDevice);
+  hip_alloc()->memcpy(w8.data(), blob.ptr<int8_t>(), nq, base::MemcpyKind::kMemcpyCPU2CUDA);
+  hip_alloc()->memcpy(sc.data(), blob.ptr<int8_t>() + nq, ns * 4, base::MemcpyKind::kMemcpyCPU2CUDA);
   op::MatmulLayer lq(kDev, Kq, Mq, /*is_quant_layer=*/true);
   lq.set_cuda_config(cfg);
   lq.set_group_size(g);
@@ -393,8 +396,14 @@ int main() {
     ++covered;
   }
   (void)hipDeviceSynchronize();
+  // every device tensor above was allocated, filled and read back through kuiper_hip_alloc.hpp and carried
+  // kDeviceHIP: the CUDA stand-in the reference sources are compiled against was never called for memory
+  REQUIRE(refstub::mem_calls() == 0);
+  const auto ps = kuiper_hip::HipMemoryPool::instance().stats();
+  REQUIRE(ps.busy_blocks == 0 && ps.idle_blocks > 0);  // every tensor released its block back to the pool
   std::printf("OK %d/8 layers: op::MatmulLayer (fp32, bias, int8), RmsNormLayer, RoPELayer, MultiHeadAttention, "
-              "SwiGLULayer, VecAddLayer, EmbeddingLayer + Layer dispatch ran forward() on libkuiper_hip.so\n",
-              covered);
+              "SwiGLULayer, VecAddLayer, EmbeddingLayer + Layer dispatch ran forward() on libkuiper_hip.so; "
+              "tensors tagged kDeviceHIP from HipDeviceAllocator (%zu pooled blocks), 0 calls into the CUDA stand-in\n",
+              covered, ps.idle_blocks);
   return covered == 8 ? 0 : 1;
 }

@@ -47,14 +47,16 @@ def test_adapter_binds_to_reference_typedefs():
 
 @pytest.mark.gpu
 def test_reference_tensor_class_through_adapter_on_gpu(gpu):
-    """The prebuilt oracle/_ref/test_ref_binding: real tensor::Tensor objects, allocated by the
-    reference's own CUDADeviceAllocator, through the thirteen get_*_kernel entry points."""
+    """The prebuilt oracle/_ref/test_ref_binding: real tensor::Tensor objects, device memory from
+    include/kuiper_hip_alloc.hpp's HipDeviceAllocator (tagged kDeviceHIP), through the thirteen get_*_kernel entry
+    points; the allocator / Tensor::to_cuda / to_cpu / CudaConfig twins checked; no memory call into the CUDA stand-in."""
     exe = build.build_ref_binding()
     if not exe or not os.path.exists(exe):
         pytest.skip("oracle/_ref/test_ref_binding was not built (needs the reference checkout)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "OK 13/13" in r.stdout, r.stdout + r.stderr
-    assert "reference tensor::Tensor + kernels_interface.h typedefs bound" in r.stdout
+    assert "kernels_interface.h typedefs bound" in r.stdout and "tagged kDeviceHIP" in r.stdout
+    assert "0 memory calls into the CUDA stand-in" in r.stdout
 
 
 def test_reference_layer_classes_link_over_hip_getters():
@@ -84,6 +86,7 @@ def test_reference_layer_classes_forward_on_gpu(gpu):
         pytest.skip("oracle/_ref/test_ref_layers was not built (needs the reference checkout)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK 8/8 layers" in r.stdout, r.stdout + r.stderr
+    assert "tagged kDeviceHIP from HipDeviceAllocator" in r.stdout and "0 calls into the CUDA stand-in" in r.stdout
 
 
 @pytest.mark.gpu
@@ -138,6 +141,51 @@ def test_demo_cli_text_prompt_with_sentencepiece_tokenizer(gpu, oracle, tmp_path
     assert lines[1].rstrip(" ") == tok.decode(want).rstrip(" ")
     spm = pytest.importorskip("sentencepiece")
     assert tok.decode(want) == spm.SentencePieceProcessor(model_file=tok_path).decode(want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ref_llama_gqa_tied", "ref_llama_mha_untied", "mid-size-tinyllama-geometry"])
+def test_reference_model_object_decodes_on_gpu(gpu, oracle, tmp_path, name):
+    """The reference's OWN model::LLama2Model - model.cpp / llama3.cpp / raw_model_data.cpp / argmax_sampler.cpp /
+    encode.cpp compiled where they lie, over its own op::*Layer classes - loads a .bin from a FILE, init(kDeviceCUDA)
+    + the demo/main.cpp loop, every operator landing in libkuiper_hip.so through the getters of INTEGRATION.md
+    (oracle/_ref/test_ref_model): the words it produces are the oracle's, on the two reference-exporter goldens and
+    on a 4-layer TinyLlama-geometry model, where the tokens/s of the reference's per-operator host loop is printed
+    next to the fused hipGraph path of this library on the same image."""
+    import torch
+    from conftest import GOLDEN, load_golden
+    from kuiperllama_amd import binfmt
+    from kuiperllama_amd.model import KuiperModel
+    exe = build.build_ref_model()
+    if exe is None or not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_ref_model not built (no reference checkout at build time)")
+    if name.startswith("ref_"):
+        spec, img, _, _ = load_golden(name)
+        steps, prompt = min(24, spec.seq_len), [1, 7, 3]
+    else:
+        spec = binfmt.ModelSpec(2048, 5632, 4, 32, 4, 32000, 256, False, binfmt.FAMILY_LLAMA, False, 64,
+                                binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, "tinyllama-4layer")
+        img = binfmt.synth_image(spec, seed=21, device=torch.device("cuda:0")).cpu().numpy()
+        steps, prompt = 64, [1, 263]
+    path = tmp_path / "m.bin"
+    img.tofile(path)
+    want = oracle.OracleModel.from_spec(img, spec).generate(prompt, steps)
+    r = subprocess.run([exe, str(path), os.path.join(GOLDEN, "spm_llama_like.model"), str(steps),
+                        ",".join(map(str, prompt)), ",".join(map(str, want))],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"OK {steps} words equal the expected ones" in r.stdout
+    ref_tok_s = float(r.stdout.split(" = ")[1].split(" tokens/s")[0])
+    if not name.startswith("ref_"):
+        m = KuiperModel.from_host_image(img, spec)
+        m.generate(prompt, steps, exec="graph")
+        words, ms = m.generate(prompt, steps, exec="graph")
+        _, ms_u = m.generate(prompt, steps, exec="unfused")
+        m.close()
+        assert words == want
+        print(f"\n{spec.name}: reference LLama2Model object on the HIP kernels {ref_tok_s:.0f} tok/s | this library, the "
+              f"reference's launch sequence (unfused) {steps / ms_u * 1e3:.0f} tok/s | fused kernels + hipGraph "
+              f"{steps / ms * 1e3:.0f} tok/s")
 
 
 @pytest.mark.gpu
