@@ -309,7 +309,7 @@ def other_config(spec, local_rank, args, steps=128):
     return out
 
 
-LONG_POSITIONS = (4095, 4096, 32768, 131071)
+LONG_POSITIONS = (1023, 2047, 4095, 4096, 32768, 131071)  # 1023 / 2047: time splits merged by k_wo_comb; from 4095: GQA group path
 
 
 def long_context(m, spec, dev):

@@ -63,10 +63,15 @@ __device__ __forceinline__ void load_u(RegsF32<U>& r, const RowsF32& rows, int c
 template <int U>
 __device__ __forceinline__ void fma_u(const RegsF32<U>& r, const f32x4* xs, int c0, int M4, int lane,
                                       int u, float& a0, float& a1) {
-  // Lanes past the end of the column range read a clamped address (load_u) and multiply by a
-  // zeroed x instead of branching around the FMAs: straight-line code keeps the compiler's
+  // Lanes past the end of the column range read a clamped address (load_u: the row's FIRST float4) and
+  // multiply by a zeroed x instead of branching around the FMAs: straight-line code keeps the compiler's
   // s_waitcnt placement exact (every exec-mask branch is a merge point where it turns conservative
-  // and waits for most of the tile), and "+ w * 0" leaves the sum bit-identical.
+  // and waits for most of the tile), and "+ w * 0" leaves the sum bit-identical - PROVIDED the first four
+  // weights of every row (int8: the first group scale) are finite, which every exported .bin satisfies
+  // (an Inf / NaN there would poison the row through 0 * Inf; the B-token prefill kernels of kh_prefill.h
+  // branch instead; tests/test_model_gpu.py::test_prefill_is_bit_identical_to_token_by_token[qwen-bias] compares the two
+  // bit for bit at dim 448 = 112 float4, i.e. with masked lanes in every row, and test_matmul_f32_vs_oracle runs M =
+  // 896 / 288 / 36 / 20000 against the oracle).
   const int idx = c0 + u * KH_WAVE + lane;
   const bool in = idx < M4;
   f32x4 xv = xs[in ? idx : 0];
@@ -243,9 +248,9 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
   static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
   const int PPW = kh_nwaves() / SPLIT;  // pairs per workgroup per iteration
   // The wave index is uniform by construction.  Telling the compiler (readfirstlane) moves the
-  // work-item arithmetic - pair index, row addresses, loop control - to the scalar unit: same-box A/B
-  // (profiles/r2_scalar_wave_ab.txt) fp32 +0.6 % (cls 154 -> 151 us, qkv 6.5 -> 6.4), but the int8
-  // kernels, whose loop is VALU-heavier, lose 0.7 % (ffn13 18.0 -> 18.4 us) - so fp32 only.
+  // work-item arithmetic - pair index, row addresses, loop control - to the scalar unit: s_cbranch_scc
+  // instead of exec masking.  (Round 2 measured it fp32-only, profiles/r2_scalar_wave_ab.txt; since the
+  // single-loop form of round 3 every loop control below depends on it, so it is unconditional.)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int part = wave & (SPLIT - 1);
   const int gp = vb * PPW + wave / SPLIT;

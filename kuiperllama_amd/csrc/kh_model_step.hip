@@ -41,10 +41,12 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
   const int elem = quant ? 1 : 4;
   const int min_bytes = quant ? 4096 : 8192;  // bytes one wave must still stream per pair
   const long pair_bytes = 2L * M * elem;
-  // waves to aim for before rows are split.  With the rolling tile refill a wave that walks several
-  // chunks of a long row keeps its loads in flight, so fewer, longer-lived waves beat many short
-  // ones (r3 sweeps, profiles/r3_shape_sweep.md: Llama-2-7B w2 int8 split 4 -> 2: 12.6 -> 10.8 us,
-  // fp32 33.6 -> 31.4; wo int8 split 2 -> 1: 5.6 -> 5.25); rounds 1-2 aimed at twice as many.
+  // waves to aim for before rows are split.  gemv_pairs walks a wave's tiles (pair, chunk) in ONE loop and
+  // requests the next tile in a burst right after the current tile's FMAs (kh_fused.h: ROLL = false everywhere but
+  // the int8 QKV kernel), so a wave that walks several chunks of a long row keeps loads in flight across them and
+  // fewer, longer-lived waves beat many short ones (r3 sweeps, profiles/r3_shape_sweep.txt: Llama-2-7B w2 int8
+  // split 4 -> 2: 12.6 -> 10.8 us, fp32 33.6 -> 31.4; wo int8 split 2 -> 1: 5.6 -> 5.25); rounds 1-2 aimed at
+  // twice as many.
   const int target_waves = pair_bytes >= 16384 ? 4096 : 2048;
   while (sh.split < max_split && pairs * sh.split < target_waves &&
          pair_bytes / (sh.split * 2) >= min_bytes)
