@@ -638,6 +638,14 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
                               hipMemcpyHostToDevice, m->stream));
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));  // `forced` is a stack-lifetime staging buffer
   const int n_forced = m->seq_cap + 1;
+  if (exec == KH_EXEC_GRAPH) {
+    // both graphs of variant 0 exist after the first generate of a model, whatever its length (a warm-up run of 5
+    // steps must leave the 8-step graph behind: capturing 656 nodes costs ~0.8 ms, which a 20-step run would
+    // otherwise pay inside its timed loop); variant 1 is captured when a run first reaches position 256
+    hipGraphExec_t ge = nullptr;
+    if ((rc = step_graph(m, n_forced, 0, false, &ge)) != KH_OK) return rc;
+    if ((rc = step_graph(m, n_forced, 0, true, &ge)) != KH_OK) return rc;
+  }
 
   // prompt phase: the tokens that are only fed (positions 0 .. n_prompt-2).  KH_PREFILL selects how:
   //   "0" / "token"  the reference's one forward pass per prompt token (demo/main.cpp:20-22)
