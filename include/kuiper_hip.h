@@ -269,7 +269,8 @@ int kh_plan_prefill_shape(int32_t epi, int32_t T, int32_t rows, int32_t K, int32
                           int32_t r2_ok, int32_t* out7);
 
 /* Tuning / test hooks.  Every hook the library honours (KH_SHAPE_<QKV|WO|FFN|W2|CLS>, KH_ATTN_WG,
- * KH_ATTN_TLONG, KH_ATTN_DEFER, KH_PREFILL, KH_PG_<CHUNK|SHAPE_*|SOLO|KZ|ATTN|ATTN_QT|ROPE_FUSE|DEBUG>,
+ * KH_ATTN_TLONG, KH_ATTN_DEFER (0 = never merge time splits in the wo kernel), KH_ATTN_DEFER_MAX (active splits up to
+ * which it does), KH_PREFILL, KH_PG_<CHUNK|SHAPE_*|SOLO|KZ|ATTN|ATTN_QT|ROPE_FUSE|DEBUG>,
  * KH_SHAPE_DEBUG) lives in ONE process-wide key -> value table, seeded once from the KH_* variables of
  * the environment when the library is first used and changed afterwards only through kh_debug_set
  * (value NULL = unset).  No launch path reads the environment.  Hooks that shape a model (KH_SHAPE_*,
