@@ -2,7 +2,7 @@
 # round 4: the persistent decode-layer engine prototype against the five-launch chain (tools/mb_engine.hip)
 cd "$(dirname "$0")/.."
 O=gpurun_out; mkdir -p $O
-B=kuiperllama_amd/lib/mb_engine
+B=${ENGINE_BIN:-kuiperllama_amd/lib/mb_engine}
 {
   for cfg in ${ENGINE_CFGS:-1b qwen tiny}; do
     for pos in ${ENGINE_POS:-64}; do
