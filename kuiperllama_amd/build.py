@@ -81,7 +81,7 @@ def build_adapter_test(force: bool = False) -> str:
     build_lib()
     inc = os.path.normpath(os.path.join(_PKG, "..", "include"))
     deps = [ADAPTER_TEST_SRC, os.path.join(os.path.dirname(ADAPTER_TEST_SRC), "adapter_cases.hpp"),
-            os.path.join(inc, "kuiper_hip_adapter.hpp"), os.path.join(inc, "kuiper_hip.h"), LIB_PATH]
+            os.path.join(inc, "kuiper_hip_adapter.hpp"), os.path.join(inc, "kuiper_hip_alloc.hpp"), os.path.join(inc, "kuiper_hip.h"), LIB_PATH]
     if (not force and os.path.exists(ADAPTER_TEST_BIN)
             and all(os.path.getmtime(d) <= os.path.getmtime(ADAPTER_TEST_BIN) for d in deps)):
         return ADAPTER_TEST_BIN
