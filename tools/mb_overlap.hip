@@ -63,6 +63,7 @@ struct OvArgs {
   int n_prod;
   int delta;  // producer's epoch relative to mine: 0 same pass, -1 the producer is the last kernel of the previous pass
   unsigned* err;
+  unsigned long long* trace;  // [4]: start / end of the first and of the last workgroup (100 MHz wall clock)
 };
 
 __device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) {
@@ -78,6 +79,9 @@ __device__ __forceinline__ void st_agent_f32(float* p, float v) {
 template <int U, int SPLIT, bool SWIGLU, bool HAND>
 __global__ __launch_bounds__(KH_WG_MAX, 4) void k_stage(const OvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tslot = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : -1);
+  unsigned long long* const trace = a.trace;
+  if (tslot >= 0 && threadIdx.x == 0) trace[tslot] = wall_clock64();
   f32x4* xs = (f32x4*)smem_raw;
   const int M = a.M, K = a.K;
   float* red = (float*)(xs + (M >> 2));
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_stage(const OvArgs a) {
     gemv_pairs<SPLIT, false>(g, xs, half, lane, red + KH_WAVES_MAX, pair, pre,
                              [&]() __attribute__((always_inline)) { st.issue(); },
                              [&]() __attribute__((always_inline)) { st.finish(xs, 1e-5f, red); }, epi);
+    if (tslot >= 0 && threadIdx.x == 0) trace[tslot + 1] = wall_clock64();
   } else {
     unsigned* const my_flag = a.my_flags + blockIdx.x;
     const unsigned* const pf = a.prod_flags;
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_stage(const OvArgs a) {
           bool ok = true;
           for (int i = lane; i < n_prod; i += KH_WAVE) ok &= ld_agent_u32(pf + i) == want;
           if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+          if (ld_agent_u32(err) != 0) break;  // somebody gave up: everybody leaves
           if (++spins > OV_POLL_LIMIT) {
             if (lane == 0) atomicOr(err, 1u);
             break;
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_stage(const OvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(my_flag, e_prev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tslot >= 0 && threadIdx.x == 0) trace[tslot + 1] = wall_clock64();
   }
 }
 
@@ -196,9 +203,14 @@ static const StageDef STAGES[5] = {
     {"w2", 2048, 8192, 8, 4, 512, 512, false, 8192},
 };
 
+// grids: the product's; one that lets any TWO consecutive kernels be resident together (VGPRs per SIMD: 80-register
+// kernels at n waves + 112-register kernels at m waves <= 512); one that lets any THREE
+static const int GRIDS[3][5] = {{768, 256, 512, 512, 512}, {768, 256, 512, 512, 256}, {512, 256, 512, 256, 256}};
+
 template <bool HAND>
-static void launch_stage(int s, const OvArgs& a, hipStream_t st) {
-  const StageDef& d = STAGES[s];
+static void launch_stage(int s, const OvArgs& a, hipStream_t st, int grid) {
+  StageDef d = STAGES[s];
+  d.grid = grid;
   const size_t lds = (size_t)d.M * 4 + 3 * KH_WAVES_MAX * sizeof(float);
   switch (s) {
     case 0: hipLaunchKernelGGL((k_stage<4, 2, false, HAND>), dim3(d.grid), dim3(d.wg), lds, st, a); break;
@@ -251,6 +263,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&flags, (size_t)NK * OV_MAX_FLAGS * 4));
   unsigned* err;
   CK(hipMalloc(&err, 4));
+  unsigned long long* trace;
+  CK(hipMalloc(&trace, (size_t)NK * 4 * 8));
 
   auto reset = [&]() {
     std::vector<float> h(16384);
@@ -260,6 +274,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(err, 0, 4));
     CK(hipDeviceSynchronize());
   };
+  int gset = 0;
   auto args_of = [&](int k) {
     const StageDef& d = STAGES[k % 5];
     const int kp = (k + NK - 1) % NK;
@@ -272,9 +287,10 @@ int main(int argc, char** argv) {
     a.M = d.M;
     a.my_flags = flags + (size_t)k * OV_MAX_FLAGS;
     a.prod_flags = flags + (size_t)kp * OV_MAX_FLAGS;
-    a.n_prod = STAGES[kp % 5].grid;
+    a.n_prod = GRIDS[gset][kp % 5];
     a.delta = k == 0 ? -1 : 0;
     a.err = err;
+    a.trace = trace + (size_t)k * 4;
     return a;
   };
 
@@ -300,59 +316,105 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 4; ++i) CK(hipEventCreateWithFlags(&evj[i], hipEventDisableTiming));
 
   std::vector<float> ref(2048), got(2048);
-  auto run_variant = [&](const char* name, bool hand, int S) {
+  auto run_variant = [&](const char* name, bool hand, int S, int gs, bool graph = true) {
+    gset = gs;
     reset();
-    hipGraph_t gr;
-    hipGraphExec_t ge;
-    CK(hipStreamBeginCapture(st[0], hipStreamCaptureModeGlobal));
-    if (S > 1) {
-      CK(hipEventRecord(evf, st[0]));
-      for (int i = 1; i < S; ++i) CK(hipStreamWaitEvent(st[i], evf, 0));
-    }
-    for (int k = 0; k < NK; ++k) {
-      const OvArgs a = args_of(k);
-      if (hand) launch_stage<true>(k % 5, a, st[k % S]);
-      else launch_stage<false>(k % 5, a, st[k % S]);
-    }
-    for (int i = 1; i < S; ++i) {
-      CK(hipEventRecord(evj[i], st[i]));
-      CK(hipStreamWaitEvent(st[0], evj[i], 0));
-    }
-    CK(hipStreamEndCapture(st[0], &gr));
-    CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
-    // 3 warm passes, then reps timed; the recurrence runs 3 + reps passes in every variant
-    for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st[0]));
-    CK(hipStreamSynchronize(st[0]));
-    CK(hipEventRecord(e0, st[0]));
-    for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st[0]));
-    CK(hipEventRecord(e1, st[0]));
-    CK(hipEventSynchronize(e1));
+    hipGraph_t gr = nullptr;
+    hipGraphExec_t ge = nullptr;
+    auto enqueue_pass = [&]() {
+      for (int k = 0; k < NK; ++k) {
+        const OvArgs a = args_of(k);
+        if (hand) launch_stage<true>(k % 5, a, st[k % S], GRIDS[gs][k % 5]);
+        else launch_stage<false>(k % 5, a, st[k % S], GRIDS[gs][k % 5]);
+      }
+    };
+    auto fork = [&]() {
+      if (S > 1) {
+        CK(hipEventRecord(evf, st[0]));
+        for (int i = 1; i < S; ++i) CK(hipStreamWaitEvent(st[i], evf, 0));
+      }
+    };
+    auto join = [&]() {
+      for (int i = 1; i < S; ++i) {
+        CK(hipEventRecord(evj[i], st[i]));
+        CK(hipStreamWaitEvent(st[0], evj[i], 0));
+      }
+    };
     float ms = 0.f;
+    if (graph) {
+      CK(hipStreamBeginCapture(st[0], hipStreamCaptureModeGlobal));
+      fork();
+      enqueue_pass();
+      join();
+      CK(hipStreamEndCapture(st[0], &gr));
+      CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+      // 3 warm passes, then reps timed; the recurrence runs 3 + reps passes in every variant
+      for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, st[0]));
+      CK(hipStreamSynchronize(st[0]));
+      CK(hipEventRecord(e0, st[0]));
+      for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, st[0]));
+      CK(hipEventRecord(e1, st[0]));
+      CK(hipEventSynchronize(e1));
+    } else {
+      // direct launches: the host runs ahead of the GPU (3-4 us per launch against ~10 us per kernel); the streams
+      // are forked once and joined once, passes follow each other without a join (the flags carry the order)
+      for (int r = 0; r < 3; ++r) enqueue_pass();
+      for (int i = 0; i < S; ++i) CK(hipStreamSynchronize(st[i]));
+      CK(hipEventRecord(e0, st[0]));
+      fork();
+      for (int r = 0; r < reps; ++r) enqueue_pass();
+      join();
+      CK(hipEventRecord(e1, st[0]));
+      CK(hipEventSynchronize(e1));
+    }
     CK(hipEventElapsedTime(&ms, e0, e1));
+
     unsigned herr = 0;
     CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(got.data(), Y[NK - 1], 2048 * 4, hipMemcpyDeviceToHost));
     const double us_pass = ms * 1e3 / reps;
     bool same = true;
-    if (!hand && S == 1) ref = got;
+    if (!hand && S == 1 && gs == 0) ref = got;
     else same = memcmp(ref.data(), got.data(), 2048 * 4) == 0;
     bool finite = true;
     for (float v : got) finite &= std::isfinite(v);
     printf("%-28s %8.1f us per pass  %6.2f us per layer  %5.2f TB/s  %s%s%s\n", name, us_pass, us_pass / L,
            wbytes / us_pass / 1e6, same ? "bits==serial" : "BITS DIFFER", herr ? "  POLL GAVE UP" : "",
            finite ? "" : "  NON-FINITE");
+    {  // timeline of one middle layer of the last pass: when did each kernel's first / last workgroup start and end
+      std::vector<unsigned long long> t((size_t)NK * 4);
+      CK(hipMemcpy(t.data(), trace, t.size() * 8, hipMemcpyDeviceToHost));
+      const int k0 = 5 * (L / 2);
+      const double base = (double)t[(size_t)k0 * 4];
+      printf("    timeline (us, layer %d):", L / 2);
+      for (int k = k0; k < k0 + 6 && k < NK; ++k) {
+        const unsigned long long* q = &t[(size_t)k * 4];
+        const double s0 = ((double)q[0] - base) / 100.0, e0_ = ((double)q[1] - base) / 100.0;
+        const double s1 = ((double)q[2] - base) / 100.0, e1_ = ((double)q[3] - base) / 100.0;
+        printf("  %s[%.1f/%.1f -> %.1f/%.1f]", STAGES[k % 5].name, s0, s1, e0_, e1_);
+      }
+      printf("\n");
+    }
     fflush(stdout);
-    CK(hipGraphExecDestroy(ge));
-    CK(hipGraphDestroy(gr));
+    if (ge) CK(hipGraphExecDestroy(ge));
+    if (gr) CK(hipGraphDestroy(gr));
     return us_pass;
   };
 
   for (int round = 0; round < 2; ++round) {
-    const double a = run_variant("serial (product form)", false, 1);
-    const double b = run_variant("serial + flag protocol", true, 1);
-    const double c2 = run_variant("overlapped, 2 streams", true, 2);
-    const double c3 = run_variant("overlapped, 3 streams", true, 3);
-    printf("  -> protocol alone %.3fx, 2 streams %.3fx, 3 streams %.3fx of the serial chain\n", b / a, c2 / a, c3 / a);
+    const double a = run_variant("serial, product grids", false, 1, 0);
+    run_variant("serial, pair-safe grids", false, 1, 1);
+    run_variant("serial, triple-safe grids", false, 1, 2);
+    const double b = run_variant("serial + flags, product grids", true, 1, 0);
+    const double c2 = run_variant("2 streams, pair-safe grids", true, 2, 1);
+    const double c2b = run_variant("2 streams, triple-safe grids", true, 2, 2);
+    const double c3 = run_variant("3 streams, triple-safe grids", true, 3, 2);
+    run_variant("direct launches, serial", false, 1, 0, false);
+    run_variant("direct, serial + flags", true, 1, 0, false);
+    run_variant("direct, 2 streams, pair-safe", true, 2, 1, false);
+    run_variant("direct, 3 streams, triple-safe", true, 3, 2, false);
+    printf("  -> of the serial chain: protocol alone %.3fx, 2 streams %.3fx / %.3fx, 3 streams %.3fx\n", b / a, c2 / a,
+           c2b / a, c3 / a);
   }
   return 0;
 }
