@@ -247,6 +247,7 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   const int tg = tid / G, dl = tid - tg * G;
   const int hs4 = hs >> 2;
   const bool active = dl < hs4;
+  const int dlc = active ? dl : 0;  // clamped lane offset: loads are unconditional, masked at the dot product
   const int stride4 = kv_stride >> 2;
   const f32x4* K4 = (const f32x4*)k_base;
   const f32x4* V4 = (const f32x4*)v_base;
@@ -255,36 +256,85 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   f32x4 q4 = zero4;
   float m = -INFINITY, l = 0.f;
   f32x4 o = zero4;
-  bool first = true;  // q is fetched behind the first batch of K/V rows (one memory round trip)
-  for (int tb = t_begin + tg; first || tb < t_end; tb += TPI * KH_ATTN_UB) {
+  // one batch = KH_ATTN_UB timesteps per lane group (K and V rows of all of them requested together)
+  auto load_batch = [&](f32x4 (&kv)[KH_ATTN_UB], f32x4 (&vv)[KH_ATTN_UB], int tb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_UB; ++u) {
+      const int t = tb + u * TPI;
+      const int tt = t < t_end ? t : t_end - 1;  // clamped address, masked in use_batch
+      // unconditional (lanes past the head vector read element 0 and are dropped in use_batch): a load behind an
+      // exec-mask branch is a CFG join, and the s_waitcnt at the loop header then degrades to vmcnt(0)
+      kv[u] = K4[(size_t)tt * stride4 + dlc];
+      vv[u] = V4[(size_t)tt * stride4 + dlc];
+    }
+  };
+  auto use_batch = [&](const f32x4 (&kv)[KH_ATTN_UB], const f32x4 (&vv)[KH_ATTN_UB], int tb)
+                       __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < KH_ATTN_UB; ++u) {
+      const int t = tb + u * TPI;
+      // lanes past the head vector hold element 0's data: their product is dropped HERE, at the first use, not by
+      // zeroing q after its load (that select was hoisted above the batch's remaining loads together with its wait)
+      const float s = group_sum<G>(active ? fma4(q4, kv[u], 0.f) : 0.f) * scale;  // all lanes: DPP, no branch
+      // Branch-free update.  A timestep past the end scores -inf: m_new = m, alpha = exp(0) = 1, p = exp(-inf) = 0, so
+      // l and o come out bit-identical to skipping it (its V row is a clamped re-read, finite).  Before the first
+      // valid timestep m = m_new = -inf; the exponent is then taken against 0 instead (alpha = p = 0 on l = o = 0)
+      // rather than forming -inf - -inf.  Valid timesteps compute exactly the expressions of the branching form.
+      // (With the update behind `if (t < t_end)` the compiler sank the batch's last V load INTO the branch, behind
+      // the first wait - a second memory round trip at every headline position.)
+      const float sm = t < t_end ? s : -INFINITY;
+      const float m_new = fmaxf(m, sm);
+      const float mref = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = expf(m - mref);  // exp(-inf) = 0 on the first timestep
+      const float p = expf(sm - mref);
+      l = l * alpha + p;
+      o.x = __builtin_fmaf(p, vv[u].x, o.x * alpha);
+      o.y = __builtin_fmaf(p, vv[u].y, o.y * alpha);
+      o.z = __builtin_fmaf(p, vv[u].z, o.z * alpha);
+      o.w = __builtin_fmaf(p, vv[u].w, o.w * alpha);
+      m = m_new;
+    }
+  };
+  const int step = TPI * KH_ATTN_UB;
+  if (t_end - t_begin <= step) {  // uniform: a single batch (every headline position) - one memory round trip
     f32x4 kv[KH_ATTN_UB], vv[KH_ATTN_UB];
-#pragma unroll
-    for (int u = 0; u < KH_ATTN_UB; ++u) {
-      const int t = tb + u * TPI;
-      const int tt = t < t_end ? t : t_end - 1;
-      kv[u] = active ? K4[(size_t)tt * stride4 + dl] : zero4;
-      vv[u] = active ? V4[(size_t)tt * stride4 + dl] : zero4;
+    q4 = ((const f32x4*)q_h)[dlc];  // same round trip as the K/V rows
+    load_batch(kv, vv, t_begin + tg);
+    __builtin_amdgcn_sched_barrier(0);  // every load has left before the first instruction that waits for one
+    use_batch(kv, vv, t_begin + tg);
+  } else {
+    // [r4] several batches: TWO register sets, the loads of batch i+2 leave when batch i has been consumed, so
+    // two batches are in flight while one is computed (the plain loop issued, waited, computed: a 256-timestep
+    // split cost two full memory round trips, a 1024-timestep one eight).  Same batches in the same order per
+    // lane group: bit-identical.  The trip count is uniform so the reloads sit in straight-line code (exact
+    // s_waitcnt); the last two batches are consumed after the loop without reloads (clamped re-reads past the end
+    // in every workgroup were 4x the real traffic at position 4094: 8.4 -> 8.8 us).
+    f32x4 ka[KH_ATTN_UB], va[KH_ATTN_UB], kb[KH_ATTN_UB], vb[KH_ATTN_UB];
+    q4 = ((const f32x4*)q_h)[dlc];
+    load_batch(ka, va, t_begin + tg);
+    load_batch(kb, vb, t_begin + tg + step);
+    __builtin_amdgcn_sched_barrier(0);
+    int base = t_begin + tg;
+    // while a third batch exists (uniform): consume, reload.  The scheduler must not interleave a batch's reloads
+    // with the other batch's arithmetic: loads moved up between the uses turned the progressive waits into
+    // vmcnt(0..1) on freshly issued loads (seen in the ISA).
+    for (; base - tg + 2 * step < t_end; base += 2 * step) {  // a third batch exists
+      use_batch(ka, va, base);
+      __builtin_amdgcn_sched_barrier(0);
+      load_batch(ka, va, base + 2 * step);
+      __builtin_amdgcn_sched_barrier(0);
+      use_batch(kb, vb, base + step);
+      __builtin_amdgcn_sched_barrier(0);
+      load_batch(kb, vb, base + 3 * step);  // past the end once when the batch count is odd: clamped re-reads
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (first) {
-      q4 = active ? ((const f32x4*)q_h)[dl] : zero4;
-      first = false;
-    }
-#pragma unroll
-    for (int u = 0; u < KH_ATTN_UB; ++u) {
-      const int t = tb + u * TPI;
-      const float s = group_sum<G>(fma4(q4, kv[u], 0.f)) * scale;  // all lanes: DPP, no branch
-      if (t < t_end) {
-        const float m_new = fmaxf(m, s);
-        const float alpha = expf(m - m_new);  // exp(-inf) = 0 on the first timestep
-        const float p = expf(s - m_new);
-        l = l * alpha + p;
-        o.x = __builtin_fmaf(p, vv[u].x, o.x * alpha);
-        o.y = __builtin_fmaf(p, vv[u].y, o.y * alpha);
-        o.z = __builtin_fmaf(p, vv[u].z, o.z * alpha);
-        o.w = __builtin_fmaf(p, vv[u].w, o.w * alpha);
-        m = m_new;
-      }
-    }
+    // the last two batches, nothing left to request (a 256-timestep split is exactly this tail); with an odd count
+    // the second one is the clamped batch - skipped (uniform), not computed through its masks.  (Tried: separate
+    // straight-line tails for "two left" / "three left" so that nothing is requested in vain - 40 % more code in a
+    // kernel whose cost is latency, slower than this at every position but the odd-count ones.)
+    use_batch(ka, va, base);
+    __builtin_amdgcn_sched_barrier(0);
+    if (base - tg + step < t_end) use_batch(kb, vb, base + step);
   }
   // ---- merge the TPI groups: common max, rescale, sum ------------------------------------
   float mw = across_groups_max<G>(m);
@@ -383,8 +433,7 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
   const int t_begin = s * TS;
   const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
   float r, L;
-  const float M = attn_fast_partial<G>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end, smem,
-                                       r, L);
+  const float M = attn_fast_partial<G>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end, smem, r, L);
   const size_t slot = (size_t)h * NSW + s;
   if (defer) {  // plain stores (also with ONE active split); the next kernel on the stream reads them
     if (tid < hs) ws.o[slot * hs + tid] = r;
@@ -457,6 +506,7 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
   const int tg = tid / G, dl = tid - tg * G;
   const int hs4 = hs >> 2;
   const bool active = dl < hs4;
+  const int dlc = active ? dl : 0;  // clamped lane offset: loads are unconditional, masked at the dot product
   const int stride4 = kv_stride >> 2;
   const f32x4* K4 = (const f32x4*)k_base;
   const f32x4* V4 = (const f32x4*)v_base;
@@ -466,27 +516,30 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
   float m[KVM], l[KVM];
 #pragma unroll
   for (int j = 0; j < KVM; ++j) {
-    q4[j] = active ? ((const f32x4*)(q_g + (size_t)j * hs))[dl] : zero4;
+    q4[j] = ((const f32x4*)(q_g + (size_t)j * hs))[dlc];  // lanes past the head vector: dropped at the dot product
     o[j] = zero4;
     m[j] = -INFINITY;
     l[j] = 0.f;
   }
-  for (int tb = t_begin + tg; tb < t_end; tb += TPI * KH_ATTN_UB) {
-    f32x4 kv[KH_ATTN_UB], vv[KH_ATTN_UB];
+  auto load_batch = [&](f32x4 (&kv)[KH_ATTN_UB], f32x4 (&vv)[KH_ATTN_UB], int tb) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < KH_ATTN_UB; ++u) {
       const int t = tb + u * TPI;
       const int tt = t < t_end ? t : t_end - 1;
-      kv[u] = active ? ld_nt(K4 + (size_t)tt * stride4 + dl) : zero4;
-      vv[u] = active ? ld_nt(V4 + (size_t)tt * stride4 + dl) : zero4;
+      kv[u] = ld_nt(K4 + (size_t)tt * stride4 + dlc);  // unconditional, see attn_fast_partial
+      vv[u] = ld_nt(V4 + (size_t)tt * stride4 + dlc);
     }
+  };
+  // tb < t_end required (u = 0 valid): a batch without any timestep would form exp2(-inf - -inf)
+  auto use_batch = [&](const f32x4 (&kv)[KH_ATTN_UB], const f32x4 (&vv)[KH_ATTN_UB], int tb)
+                       __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < KVM; ++j) {
       float sv[KH_ATTN_UB];
       float mx = m[j];
 #pragma unroll
       for (int u = 0; u < KH_ATTN_UB; ++u) {
-        sv[u] = group_sum<G>(fma4(q4[j], kv[u], 0.f)) * sc2;  // all lanes: DPP, no branch
+        sv[u] = group_sum<G>(active ? fma4(q4[j], kv[u], 0.f) : 0.f) * sc2;  // all lanes: DPP, no branch
         if (tb + u * TPI < t_end) mx = fmaxf(mx, sv[u]);       // u = 0 is always valid
       }
       const float alpha = __builtin_amdgcn_exp2f(m[j] - mx);  // exp2(-inf) = 0 on the first batch
@@ -494,19 +547,42 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
       f32x4 oj = o[j] * alpha;
 #pragma unroll
       for (int u = 0; u < KH_ATTN_UB; ++u) {
-        if (tb + u * TPI < t_end) {
-          const float p = __builtin_amdgcn_exp2f(sv[u] - mx);
-          lj += p;
-          oj.x = __builtin_fmaf(p, vv[u].x, oj.x);
-          oj.y = __builtin_fmaf(p, vv[u].y, oj.y);
-          oj.z = __builtin_fmaf(p, vv[u].z, oj.z);
-          oj.w = __builtin_fmaf(p, vv[u].w, oj.w);
-        }
+        // branch-free: a timestep past the end contributes p = 0 (its V row is a clamped re-read, finite), which
+        // leaves lj and oj bit-identical to skipping it; mx is finite here (u = 0 is valid)
+        const float p = tb + u * TPI < t_end ? __builtin_amdgcn_exp2f(sv[u] - mx) : 0.f;
+        lj += p;
+        oj.x = __builtin_fmaf(p, vv[u].x, oj.x);
+        oj.y = __builtin_fmaf(p, vv[u].y, oj.y);
+        oj.z = __builtin_fmaf(p, vv[u].z, oj.z);
+        oj.w = __builtin_fmaf(p, vv[u].w, oj.w);
       }
       l[j] = lj;
       o[j] = oj;
       m[j] = mx;
     }
+  };
+  // [r4] two register sets, see attn_fast_partial: the loads of batch i+2 leave when batch i has been consumed
+  // (this path starts at 4096 timesteps, i.e. always has many batches per workgroup); uniform trip count.
+  {
+    const int step = TPI * KH_ATTN_UB;
+    f32x4 ka[KH_ATTN_UB], va[KH_ATTN_UB], kb[KH_ATTN_UB], vb[KH_ATTN_UB];
+    load_batch(ka, va, t_begin + tg);
+    load_batch(kb, vb, t_begin + tg + step);
+    __builtin_amdgcn_sched_barrier(0);
+    int base = t_begin + tg;
+    for (; base - tg + 2 * step < t_end; base += 2 * step) {  // while a third batch exists (uniform)
+      if (base < t_end) use_batch(ka, va, base);
+      __builtin_amdgcn_sched_barrier(0);
+      load_batch(ka, va, base + 2 * step);
+      __builtin_amdgcn_sched_barrier(0);
+      if (base + step < t_end) use_batch(kb, vb, base + step);
+      __builtin_amdgcn_sched_barrier(0);
+      load_batch(kb, vb, base + 3 * step);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (base < t_end) use_batch(ka, va, base);  // the last two batches: nothing left to request
+    __builtin_amdgcn_sched_barrier(0);
+    if (base + step < t_end) use_batch(kb, vb, base + step);
   }
   // ---- merge the lane groups of a wave, then the waves -----------------------------------------
 #pragma unroll
@@ -634,6 +710,11 @@ __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem
 // once pos + 1 >= t_long.  The choice is uniform over the grid (it depends on the position
 // only), so one captured launch serves every position; workgroups beyond the active path's
 // count leave immediately.
+// (Measured and not kept, profiles/r4_attn_pipe_ab.txt: the split-0 workgroups requesting q and their first batch -
+// rows tg + u * TPI whatever the position is - BEFORE the device scalar *d_pos has arrived.  The position then has to
+// come through a vector load (scalar loads return out of order, so the kernel-argument waits would wait for it), the
+// rows past the position are cold HBM rows instead of clamped re-reads, and the wait covers both: 3.9 -> 4.4-4.6 us
+// at position 63.)
 template <int G, int KVM>
 __global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(KhAttnArgs a, int host_pos) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -730,6 +811,10 @@ static inline int attn_tlong_hook() {
 static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStream_t s,
                                       int ntok = 1, int pos_hi = -1) {
   const int G = attn_lanes(a.head_size);
+  // host-positioned launch whose positions all stay below the group path's threshold: the per-head-only
+  // instantiation (fewer registers: two 512-thread workgroups per CU instead of one, which matters when 16 splits
+  // x 32 heads are in flight).  Device-positioned callers clear nsplit_g themselves when they know the range.
+  if (!a.d_pos && (pos_hi >= 0 ? pos_hi : host_pos) + 1 < a.t_long) a.nsplit_g = 0;
   const bool grp = a.nsplit_g > 0 && attn_group_supported(a.head_size, a.kv_mul, wg);
   if (!grp) a.nsplit_g = 0;
   int head_splits = a.nsplit, group_splits = grp ? a.nsplit_g : 0;

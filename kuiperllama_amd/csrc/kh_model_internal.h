@@ -25,6 +25,7 @@ struct LayerW {
 }  // namespace khm
 using khm::LayerW;
 
+#define KH_STEP_VARIANTS 3  // kh_model_step.hip::step_variant
 struct kh_model {
   kh_config cfg{};
   kh_model_opts opts{};
@@ -88,7 +89,7 @@ struct kh_model {
     hipGraph_t g = nullptr;
     hipGraphExec_t e = nullptr;
   };
-  StepGraph sg1[2], sgN[2];  // [variant]: one step, KH_GRAPH_STEPS steps
+  StepGraph sg1[KH_STEP_VARIANTS], sgN[KH_STEP_VARIANTS];  // [variant]: one step, KH_GRAPH_STEPS steps
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 

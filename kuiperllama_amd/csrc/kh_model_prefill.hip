@@ -191,6 +191,7 @@ void launch_prefill_chunk(kh_model* m, const int32_t* toks, int nvalid, int pos0
     {
       KhAttnArgs a = fill_attn(m, l);
       a.defer = 0;  // multi-token slices merge in the launch
+      a.nsplit_g = m->attn_ns_g;  // not the decode step's variant: launch_attn_decode decides from the slice's positions
       a.q = m->pf_q;
       a.out = m->pf_att;
       a.d_pos = nullptr;
@@ -467,6 +468,7 @@ void launch_prefill_gemm_chunk(kh_model* m, const int32_t* toks, int T, int pos0
     } else {
       KhAttnArgs a = fill_attn(m, l);
       a.defer = 0;  // multi-token slices merge in the launch
+      a.nsplit_g = m->attn_ns_g;  // not the decode step's variant: launch_attn_decode decides from the slice's positions
       a.q = m->pg_q;
       a.out = m->pg_att;
       a.d_pos = nullptr;

@@ -206,7 +206,9 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   a.nsplit = m->attn_ns;
   a.ws = m->attn_ws;
   a.ws_stride = m->attn_ws_stride;
-  a.nsplit_g = m->attn_ns_g;
+  // step variants 1 and 2 cover positions below the group path's threshold only (step_variant): launch the
+  // per-head-only instantiation, whose register count leaves room for two 512-thread workgroups per CU
+  a.nsplit_g = m->step_var != 0 ? 0 : m->attn_ns_g;
   a.t_long = m->attn_t_long;
   a.defer = m->step_var == 1 ? 1 : 0;
   a.tok_stride = 0;
@@ -363,12 +365,15 @@ void launch_sample(kh_model* m, int advance, int n_forced) {
 // model, +3.3 us), so shapes whose staging cannot hide under wo's first weight tile (kh_fused.h:
 // OVERLAP) defer only up to 4 splits (profiles/r4_attn_defer_ab.txt: Llama-2-7B int8 loses from 8 on).
 int step_variant(const kh_model* m, int pos_lo, int pos_hi) {
-  if (!m->attn_defer) return 0;
+  (void)pos_lo;
   if (pos_hi < KH_ATTN_MIN_TS) return 0;         // pos + 1 <= 256 everywhere: one split
   if (pos_hi + 1 >= m->attn_t_long) return 0;    // some step runs the group path
-  if (attn_active_splits(pos_hi, m->attn_ns) > m->attn_defer_max) return 0;
-  (void)pos_lo;
-  return 1;
+  if (m->attn_defer && attn_active_splits(pos_hi, m->attn_ns) <= m->attn_defer_max) return 1;
+  // Variant 2: the merge stays in the attention launch, but every step of the range is below the group path's
+  // threshold, so the launch uses the per-head-only instantiation.  The one that also carries the group path needs
+  // 138+ registers (two K/V batches in flight for kv_mul heads): one 512-thread workgroup per CU, which cost the 512
+  // (head, split) workgroups at position 4094 +3.6 us per layer (profiles/r4_attn_pipe_ab.txt); per-head-only: 115.
+  return m->attn_ns_g > 0 ? 2 : 0;
 }
 // one fused decode step = 5L + 2 launches.  ev (optional) receives an event after each launch.
 void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev, int variant) {
@@ -476,7 +481,7 @@ int ensure_seq_cap(kh_model* m, int n) {
 }
 void destroy_step_graphs(kh_model* m) {
   for (auto* set : {m->sg1, m->sgN})
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < KH_STEP_VARIANTS; ++v) {
       if (set[v].e) (void)hipGraphExecDestroy(set[v].e);
       if (set[v].g) (void)hipGraphDestroy(set[v].g);
       set[v] = kh_model::StepGraph{};
@@ -492,9 +497,10 @@ int capture_steps(kh_model* m, int n_forced, int steps, int variant, hipGraph_t*
   return KH_OK;
 }
 int step_graph(kh_model* m, int n_forced, int variant, bool steps8, hipGraphExec_t* out) {
-  kh_model::StepGraph& sg = (steps8 ? m->sgN : m->sg1)[variant ? 1 : 0];
+  if (variant < 0 || variant >= KH_STEP_VARIANTS) return KH_ERR_INVALID_ARG;
+  kh_model::StepGraph& sg = (steps8 ? m->sgN : m->sg1)[variant];
   if (!sg.e) {
-    const int rc = capture_steps(m, n_forced, steps8 ? KH_GRAPH_STEPS : 1, variant ? 1 : 0, &sg.g, &sg.e);
+    const int rc = capture_steps(m, n_forced, steps8 ? KH_GRAPH_STEPS : 1, variant, &sg.g, &sg.e);
     if (rc != KH_OK) return rc;
   }
   *out = sg.e;

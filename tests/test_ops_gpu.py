@@ -391,6 +391,41 @@ def test_mha_decode_time_split(gpu, oracle):
         assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
 
 
+@pytest.mark.parametrize("heads,kv_heads,hs", [(8, 8, 64), (8, 2, 64), (4, 4, 128), (6, 6, 48)])
+def test_mha_decode_batch_pipeline_edges(gpu, oracle, heads, kv_heads, hs):
+    """The decode kernel keeps TWO batches of K/V rows in flight (a batch = 4 timesteps per lane group = 128
+    timesteps of a 512-thread workgroup at head size 64, 64 at 128): single-batch path, exactly two, the
+    reload loop, odd batch counts whose last reload is a clamped batch that is skipped, partial last batches.
+    Positions walk every one of those edges on the per-head path (split length 256 up to 4096 timesteps, then
+    320 / 384 / 448 / 512 / 576), each against the oracle, with every cache row PAST the position set to NaN -
+    clamped loads must never leave the valid rows, masked lanes must never leak into the result (head size 48:
+    a quarter of every lane group is past the head vector)."""
+    from kuiperllama_amd import ops
+    seq = 9000
+    rng = np.random.default_rng(heads * 31 + hs)
+    kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+    kc = rng.standard_normal((1, seq, kv_dim)).astype(np.float32)
+    vc = rng.standard_normal((1, seq, kv_dim)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    kc[0, 4500, :hs] = 2.0 * q[:hs]
+    ws = ops.mha_decode_workspace(heads, hs, seq, gpu)
+    kcd, vcd, qd = dev(kc, gpu), dev(vc, gpu), dev(q, gpu)
+    positions = [0, 1, 62, 63, 64, 126, 127, 128, 129, 191, 192, 254, 255, 256, 257, 383, 384, 385, 511, 512, 639,
+                 640, 1279, 4094, 4095, 4096, 4097, 5119, 5120, 5121, 6143, 6144, 7167, 7168, 8191, 8192, 8999]
+    for pos in positions:
+        kp, vp = kcd.clone(), vcd.clone()
+        kp[:, pos + 1:] = float("nan")
+        vp[:, pos + 1:] = float("nan")
+        out = torch.full((dim,), float("nan"), device=gpu)
+        ops.mha_decode(torch.tensor([pos], dtype=torch.int32, device=gpu), heads, 0, seq, kv_dim, kv_mul, hs, out,
+                       qd, kp, vp, ws)
+        oo, _ = oracle.mha(pos, heads, 0, seq, kv_dim, kv_mul, hs, q, kc, vc, acc=oracle.ACC_F64)
+        got = host(out)
+        assert np.isfinite(got).all(), f"pos {pos}: a row past the position reached the result"
+        np.testing.assert_allclose(got, oo, rtol=0, atol=3e-5, err_msg=f"heads {heads}/{kv_heads} hs {hs} pos {pos}")
+    assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
+
+
 @pytest.mark.parametrize("heads,kv_heads,hs", [(8, 2, 64), (14, 2, 64), (16, 2, 64), (4, 2, 64),
                                                (8, 2, 128), (4, 2, 128)])
 def test_mha_decode_gqa_group_path(gpu, oracle, heads, kv_heads, hs, monkeypatch):
