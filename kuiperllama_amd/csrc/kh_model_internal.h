@@ -82,14 +82,15 @@ struct kh_model {
   // the decode step captured once as a 1-step graph and once as a KH_GRAPH_STEPS-step graph:
   // consecutive hipGraphLaunch calls leave the GPU idle for ~8 us (measured), so the long
   // graph amortises that gap over several tokens
-  // ... each in two VARIANTS of the attention / wo pair (kh_model_step.hip::step_variant): 0 = the
+  // ... each in three VARIANTS of the attention / wo pair (kh_model_step.hip::step_variant): 0 = the
   // attention launch merges its time splits itself (valid at every position; nothing to merge below
-  // position 256), 1 = the splits are merged by k_wo_comb (positions on the per-head path only)
+  // position 256), 1 = the splits are merged by k_wo_comb (positions on the per-head path only), 2 = as 0
+  // with the per-head-only attention instantiation (positions below the group path, merge not deferrable)
   struct StepGraph {
     hipGraph_t g = nullptr;
     hipGraphExec_t e = nullptr;
   };
-  StepGraph sg1[KH_STEP_VARIANTS], sgN[KH_STEP_VARIANTS];  // [variant]: one step, KH_GRAPH_STEPS steps
+  StepGraph sg[KH_STEP_VARIANTS][4];  // [variant][log2 steps]: graphs of 1, 2, 4 and KH_GRAPH_STEPS = 8 steps
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -117,7 +118,7 @@ void launch_ffn13(kh_model* m, int l);
 void launch_w2(kh_model* m, int l);
 void launch_cls(kh_model* m);
 void launch_sample(kh_model* m, int advance, int n_forced);
-// variant (see kh_model::sg1): which attention / wo pair the launches of a step use
+// variant (see kh_model::sg): which attention / wo pair the launches of a step use
 int step_variant(const kh_model* m, int pos_lo, int pos_hi);
 void launch_step_fused(kh_model* m, int advance, int n_forced, hipEvent_t* ev, int variant);
 int launch_step_unfused(kh_model* m, int pos);
@@ -127,6 +128,8 @@ int ensure_seq_cap(kh_model* m, int n);
 void destroy_step_graphs(kh_model* m);
 // the captured graph of 1 (steps8 = false) or KH_GRAPH_STEPS decode steps in `variant`, captured on first use
 int step_graph(kh_model* m, int n_forced, int variant, bool steps8, hipGraphExec_t* out);
+// the same for a graph of `nsteps` in {1, 2, 4, 8} steps (the tail of a run: 20 steps = 8 + 8 + 4)
+int step_graph_n(kh_model* m, int n_forced, int variant, int nsteps, hipGraphExec_t* out);
 // ---- kh_model_prefill.hip -------------------------------------------------------------------
 bool prefill_supported(const kh_model* m);  // B-token VALU path
 bool pg_supported(const kh_model* m);       // MFMA GEMM path

@@ -480,11 +480,12 @@ int ensure_seq_cap(kh_model* m, int n) {
   return KH_OK;
 }
 void destroy_step_graphs(kh_model* m) {
-  for (auto* set : {m->sg1, m->sgN})
-    for (int v = 0; v < KH_STEP_VARIANTS; ++v) {
-      if (set[v].e) (void)hipGraphExecDestroy(set[v].e);
-      if (set[v].g) (void)hipGraphDestroy(set[v].g);
-      set[v] = kh_model::StepGraph{};
+  for (int v = 0; v < KH_STEP_VARIANTS; ++v)
+    for (int k = 0; k < 4; ++k) {
+      kh_model::StepGraph& sg = m->sg[v][k];
+      if (sg.e) (void)hipGraphExecDestroy(sg.e);
+      if (sg.g) (void)hipGraphDestroy(sg.g);
+      sg = kh_model::StepGraph{};
     }
 }
 
@@ -496,15 +497,20 @@ int capture_steps(kh_model* m, int n_forced, int steps, int variant, hipGraph_t*
   KH_CHECK_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
   return KH_OK;
 }
-int step_graph(kh_model* m, int n_forced, int variant, bool steps8, hipGraphExec_t* out) {
+int step_graph_n(kh_model* m, int n_forced, int variant, int nsteps, hipGraphExec_t* out) {
   if (variant < 0 || variant >= KH_STEP_VARIANTS) return KH_ERR_INVALID_ARG;
-  kh_model::StepGraph& sg = (steps8 ? m->sgN : m->sg1)[variant];
+  const int k = nsteps == 1 ? 0 : nsteps == 2 ? 1 : nsteps == 4 ? 2 : nsteps == KH_GRAPH_STEPS ? 3 : -1;
+  if (k < 0) return KH_ERR_INVALID_ARG;
+  kh_model::StepGraph& sg = m->sg[variant][k];
   if (!sg.e) {
-    const int rc = capture_steps(m, n_forced, steps8 ? KH_GRAPH_STEPS : 1, variant, &sg.g, &sg.e);
+    const int rc = capture_steps(m, n_forced, nsteps, variant, &sg.g, &sg.e);
     if (rc != KH_OK) return rc;
   }
   *out = sg.e;
   return KH_OK;
+}
+int step_graph(kh_model* m, int n_forced, int variant, bool steps8, hipGraphExec_t* out) {
+  return step_graph_n(m, n_forced, variant, steps8 ? KH_GRAPH_STEPS : 1, out);
 }
 
 void plan_decode_shapes(bool quant, int dim, int hidden_dim, int kv_dim, int vocab_size,
@@ -645,12 +651,13 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));  // `forced` is a stack-lifetime staging buffer
   const int n_forced = m->seq_cap + 1;
   if (exec == KH_EXEC_GRAPH) {
-    // both graphs of variant 0 exist after the first generate of a model, whatever its length (a warm-up run of 5
-    // steps must leave the 8-step graph behind: capturing 656 nodes costs ~0.8 ms, which a 20-step run would
-    // otherwise pay inside its timed loop); variant 1 is captured when a run first reaches position 256
+    // all four graphs of variant 0 (1 / 2 / 4 / 8 steps) exist after the first generate of a model, whatever its
+    // length (a warm-up run of 5 steps must leave the 8-step graph behind: capturing 656 nodes costs ~0.8 ms, which a
+    // 20-step run would otherwise pay inside its timed loop); the other variants are captured when a run first
+    // reaches position 256
     hipGraphExec_t ge = nullptr;
-    if ((rc = step_graph(m, n_forced, 0, false, &ge)) != KH_OK) return rc;
-    if ((rc = step_graph(m, n_forced, 0, true, &ge)) != KH_OK) return rc;
+    for (int n = 1; n <= KH_GRAPH_STEPS; n *= 2)
+      if ((rc = step_graph_n(m, n_forced, 0, n, &ge)) != KH_OK) return rc;
   }
 
   // prompt phase: the tokens that are only fed (positions 0 .. n_prompt-2).  KH_PREFILL selects how:
@@ -682,10 +689,12 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   set_state(m, h_prompt[start], start);
   auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps (positions s ..)
     if (exec == KH_EXEC_GRAPH) {
-      const bool n8 = total_steps - s >= KH_GRAPH_STEPS;
-      const int n = n8 ? KH_GRAPH_STEPS : 1;
+      // the largest of 8 / 4 / 2 / 1 steps that still fits (a single-step launch costs ~15 us of graph-launch gap:
+      // the 20-step form of the bench ran 8 + 8 + 1 + 1 + 1 + 1 and lost 0.3 % to it; now 8 + 8 + 4)
+      int n = KH_GRAPH_STEPS;
+      while (n > total_steps - s) n >>= 1;
       hipGraphExec_t ge = nullptr;
-      if (step_graph(m, n_forced, step_variant(m, s, s + n - 1), n8, &ge) != KH_OK) return -1;
+      if (step_graph_n(m, n_forced, step_variant(m, s, s + n - 1), n, &ge) != KH_OK) return -1;
       if (hipGraphLaunch(ge, m->stream) != hipSuccess) return -1;
       return n;
     }
