@@ -422,7 +422,10 @@ def test_mha_decode_batch_pipeline_edges(gpu, oracle, heads, kv_heads, hs):
         oo, _ = oracle.mha(pos, heads, 0, seq, kv_dim, kv_mul, hs, q, kc, vc, acc=oracle.ACC_F64)
         got = host(out)
         assert np.isfinite(got).all(), f"pos {pos}: a row past the position reached the result"
-        np.testing.assert_allclose(got, oo, rtol=0, atol=3e-5, err_msg=f"heads {heads}/{kv_heads} hs {hs} pos {pos}")
+        # fp32 round-off of up to 9000 accumulated terms against the float64 oracle: 3e-5 absolute as everywhere in
+        # this file, plus 2e-5 relative for the head that sees the dominant key (|out| up to 3.4 there)
+        np.testing.assert_allclose(got, oo, rtol=2e-5, atol=3e-5,
+                                   err_msg=f"heads {heads}/{kv_heads} hs {hs} pos {pos}")
     assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
 
 
