@@ -372,13 +372,6 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
 // stale L1 / scalar-cache line).  Loads are issued in batches of KH_ATTN_MB before any is
 // used, so the merge costs nact/KH_ATTN_MB memory round trips instead of nact.
 #define KH_ATTN_MB 16
-// AGENT = false: the partials were written by an EARLIER launch (k_attn_merge): plain loads, L2 hits.
-template <bool AGENT>
-__device__ __forceinline__ float ld_partial(const float* p) {
-  if constexpr (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-template <bool AGENT = true>
 __device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h, int e, int hs,
                                                    int nact, int NSW) {
   const size_t base = (size_t)h * NSW;
@@ -388,7 +381,7 @@ __device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h,
 #pragma unroll
     for (int u = 0; u < KH_ATTN_MB; ++u) {
       const int k = k0 + u < nact ? k0 + u : nact - 1;
-      mv[u] = ld_partial<AGENT>(&ws.ml[(base + k) * 2]);
+      mv[u] = __hip_atomic_load(&ws.ml[(base + k) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int u = 0; u < KH_ATTN_MB; ++u) Mx = fmaxf(Mx, mv[u]);
@@ -400,9 +393,9 @@ __device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h,
     for (int u = 0; u < KH_ATTN_MB; ++u) {
       const int k = k0 + u < nact ? k0 + u : nact - 1;
       const size_t sl = base + k;
-      mv[u] = ld_partial<AGENT>(&ws.ml[sl * 2]);
-      lv[u] = ld_partial<AGENT>(&ws.ml[sl * 2 + 1]);
-      ov[u] = ld_partial<AGENT>(&ws.o[sl * hs + e]);
+      mv[u] = __hip_atomic_load(&ws.ml[sl * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lv[u] = __hip_atomic_load(&ws.ml[sl * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ov[u] = __hip_atomic_load(&ws.o[sl * hs + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int u = 0; u < KH_ATTN_MB; ++u) {
@@ -637,7 +630,7 @@ template <int G, int KVM>
 __device__ __forceinline__ void attn_group_decode(const float* q_g, const float* k_base,
                                                   const float* v_base, int kv_stride, int hs,
                                                   int pos, float* out_g, float* smem, int g, int s,
-                                                  int NS, int NSW, AttnSplitWs ws, bool defer) {
+                                                  int NS, int NSW, AttnSplitWs ws) {
   const int tid = threadIdx.x;
   const int nT = pos + 1;
   const int TS = attn_split_len(nT, NS);
@@ -650,21 +643,11 @@ __device__ __forceinline__ void attn_group_decode(const float* q_g, const float*
   const bool mine = tid < KVM * hs;
   const int j = mine ? tid / hs : 0, e = tid - j * hs;
   const int h = g * KVM + j;
-  const size_t slot = (size_t)h * NSW + s;
-  if (defer) {  // plain stores (also with ONE active split); a later launch merges (k_attn_merge)
-    if (mine) {
-      ws.o[slot * hs + e] = r;
-      if (e == 0) {
-        ws.ml[slot * 2] = M;
-        ws.ml[slot * 2 + 1] = L;
-      }
-    }
-    return;
-  }
   if (nact == 1) {
     if (mine) out_g[(size_t)j * hs + e] = r / L;
     return;
   }
+  const size_t slot = (size_t)h * NSW + s;
   if (mine) {  // write-through publication, see attn_head_decode_fast
     st_agent(&ws.o[slot * hs + e], r);
     if (e == 0) {
@@ -700,7 +683,7 @@ struct KhAttnArgs {
   int ws_stride;           // split slots per head in the workspace (>= nsplit, >= nsplit_g)
   int nsplit_g;            // GQA long-context path: kv_heads * nsplit_g workgroups (0 = off)
   int t_long;              // the group path runs when pos + 1 >= t_long
-  int defer;               // leave the split partials (also a single one) for k_wo_comb (per-head path only) or k_attn_merge
+  int defer;               // per-head path: leave the split partials (also a single one) for k_wo_comb
   // prefill (kh_prefill.h): gridDim.y tokens per launch, token t at position pos + t, its q /
   // out rows tok_stride floats apart, its split workspace ws_tok_bytes apart (decode: y = 1)
   int tok_stride;
@@ -756,32 +739,8 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(KhAttnArgs a, int hos
                               a.vcache_layer + head_off, a.kv_dim, a.head_size, pos,
                               a.out + (size_t)g * KVM * a.head_size, (float*)smem_raw, g, s,
                               a.nsplit_g, a.ws_stride,
-                              attn_ws_carve(a.ws, a.kv_heads * KVM, a.head_size, a.ws_stride), a.defer != 0);
+                              attn_ws_carve(a.ws, a.kv_heads * KVM, a.head_size, a.ws_stride));
   }
-}
-
-// [r4] The split merge as a launch of its own (step variants 3 / 4, kh_model_step.hip::step_variant): the attention
-// launch runs with defer = 1 (plain stores, no publish -> ticket -> last-arriver chain), this kernel - one workgroup
-// per head, one thread per element - reads the partials with PLAIN loads (an earlier launch wrote them: L2 hits at
-// ~0.15 us instead of three agent-scope hops at 1.3-1.5 us each) and writes the head's final vector; wo then stages it
-// plainly.  Costs one more dependent launch (1.55 us floor) and wins wherever the in-launch chain (~4.5 us) or the
-// re-read of all partials by every wo workgroup (k_wo_comb: +2.4 us at 8 splits, +3.3 at 16) costs more than that.
-// The arithmetic is attn_merge_splits's: bit-identical to the other two forms.
-struct KhAttnMergeArgs {
-  void* ws;
-  float* out;  // [heads * head_size]
-  const int32_t* d_pos;
-  int heads, head_size, ws_stride;
-  int nsplit, nsplit_g, t_long;  // as in KhAttnArgs: which path produced the partials at this position
-};
-static __global__ __launch_bounds__(256) void k_attn_merge(const KhAttnMergeArgs a) {
-  const int pos = *a.d_pos;
-  const int h = (int)blockIdx.x, e = (int)threadIdx.x;
-  const bool grp = a.nsplit_g > 0 && pos + 1 >= a.t_long;
-  const int nact = attn_active_splits(pos, grp ? a.nsplit_g : a.nsplit);
-  if (e >= a.head_size) return;
-  const AttnSplitWs ws = attn_ws_carve(a.ws, a.heads, a.head_size, a.ws_stride);
-  a.out[(size_t)h * a.head_size + e] = attn_merge_splits<false>(ws, h, e, a.head_size, nact, a.ws_stride);
 }
 
 // lanes cooperating on one timestep for this head size

@@ -25,7 +25,7 @@ struct LayerW {
 }  // namespace khm
 using khm::LayerW;
 
-#define KH_STEP_VARIANTS 5  // kh_model_step.hip::step_variant
+#define KH_STEP_VARIANTS 3  // kh_model_step.hip::step_variant
 struct kh_model {
   kh_config cfg{};
   kh_model_opts opts{};
@@ -55,8 +55,6 @@ struct kh_model {
   int attn_wg = KH_WG;
   bool attn_defer = false;  // variant 1 exists: split partials combined by kh_fused.h::k_wo_comb
   int attn_defer_max = 0;   // ... up to this many active splits (more: the in-launch merge is as fast or faster)
-  bool attn_merge_launch = false;  // variants 3 / 4 exist: the split merge as a launch of its own (k_attn_merge) ...
-  int attn_merge_from = 8;         // ... from this many active splits on the per-head path, and on the whole group path
   int step_var = 0;         // variant the launch_* helpers use right now (set by launch_step_fused / profile)
   int32_t *d_pos = nullptr, *d_token = nullptr, *d_next = nullptr, *d_forced = nullptr,
           *d_words = nullptr;
@@ -84,12 +82,10 @@ struct kh_model {
   // the decode step captured once as a 1-step graph and once as a KH_GRAPH_STEPS-step graph:
   // consecutive hipGraphLaunch calls leave the GPU idle for ~8 us (measured), so the long
   // graph amortises that gap over several tokens
-  // ... each in VARIANTS of the attention / wo pair (kh_model_step.hip::step_variant): 0 = the attention
-  // launch merges its time splits itself (valid at every position; nothing to merge below position 256),
-  // 1 = the splits are merged by k_wo_comb (positions on the per-head path only), 2 = as 0 with the
-  // per-head-only attention instantiation (positions below the group path), 3 / 4 = the merge is a launch of
-  // its own between attention and wo (k_attn_merge; 3: per-head-only attention instantiation, 4: the one that
-  // also carries the GQA group path)
+  // ... each in three VARIANTS of the attention / wo pair (kh_model_step.hip::step_variant): 0 = the
+  // attention launch merges its time splits itself (valid at every position; nothing to merge below
+  // position 256), 1 = the splits are merged by k_wo_comb (positions on the per-head path only), 2 = as 0
+  // with the per-head-only attention instantiation (positions below the group path, merge not deferrable)
   struct StepGraph {
     hipGraph_t g = nullptr;
     hipGraphExec_t e = nullptr;

@@ -275,10 +275,6 @@ int finish_create(kh_model* m) {
     m->attn_defer_max = overlap ? KH_ATTN_MAX_NS : 4;
     if (const char* e = dbg("KH_ATTN_DEFER_MAX")) m->attn_defer_max = atoi(e);
   }
-  // step variants 3 / 4 - the split merge as a launch of its own (kh_attn.h::k_attn_merge)
-  m->attn_merge_launch = c.head_size > 32 && c.head_size <= 256 && m->attn_ws_stride > 1 &&
-                         !(m->opts.flags & KH_FLAG_ATTN_MERGE_IN_LAUNCH) && !dbg_off("KH_ATTN_MERGE_LAUNCH");
-  if (const char* e = dbg("KH_ATTN_MERGE_FROM")) m->attn_merge_from = atoi(e);
   if (const size_t wsb = attn_ws_bytes(c.head_num, c.head_size, m->attn_ws_stride)) {
     KH_CHECK_HIP(hipMalloc(&m->attn_ws, wsb));
     KH_CHECK_HIP(hipMemsetAsync(m->attn_ws, 0, wsb, m->stream));

@@ -206,11 +206,11 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   a.nsplit = m->attn_ns;
   a.ws = m->attn_ws;
   a.ws_stride = m->attn_ws_stride;
-  // step variants 1, 2 and 3 cover positions below the group path's threshold only (step_variant): launch the
+  // step variants 1 and 2 cover positions below the group path's threshold only (step_variant): launch the
   // per-head-only instantiation, whose register count leaves room for two 512-thread workgroups per CU
-  a.nsplit_g = (m->step_var == 0 || m->step_var == 4) ? m->attn_ns_g : 0;
+  a.nsplit_g = m->step_var != 0 ? 0 : m->attn_ns_g;
   a.t_long = m->attn_t_long;
-  a.defer = (m->step_var == 1 || m->step_var >= 3) ? 1 : 0;
+  a.defer = m->step_var == 1 ? 1 : 0;
   a.tok_stride = 0;
   a.ws_tok_bytes = 0;
   return a;
@@ -229,20 +229,6 @@ void launch_attn(kh_model* m, int l) {
   else  // head_size <= 32: generic LDS-score kernel (tiny test models)
     hipLaunchKernelGGL(k_attn_generic, dim3(c.head_num), dim3(wg),
                        attn_lds_bytes(c.head_size, wg), m->stream, a);
-  if (m->step_var >= 3) {  // the split merge as a launch of its own (kh_attn.h::k_attn_merge)
-    KhAttnMergeArgs g;
-    g.ws = m->attn_ws;
-    g.out = m->att;
-    g.d_pos = m->d_pos;
-    g.heads = c.head_num;
-    g.head_size = c.head_size;
-    g.ws_stride = m->attn_ws_stride;
-    g.nsplit = m->attn_ns;
-    g.nsplit_g = a.nsplit_g;
-    g.t_long = m->attn_t_long;
-    hipLaunchKernelGGL(k_attn_merge, dim3(c.head_num), dim3(c.head_size <= 64 ? 64 : (c.head_size <= 128 ? 128 : 256)),
-                       0, m->stream, g);
-  }
 }
 KhGemvResArgs fill_wo(kh_model* m, int l) {
   const kh_config& c = m->cfg;
@@ -380,21 +366,13 @@ void launch_sample(kh_model* m, int advance, int n_forced) {
 // OVERLAP) defer only up to 4 splits (profiles/r4_attn_defer_ab.txt: Llama-2-7B int8 loses from 8 on).
 int step_variant(const kh_model* m, int pos_lo, int pos_hi) {
   (void)pos_lo;
-  if (pos_hi < KH_ATTN_MIN_TS) return 0;  // pos + 1 <= 256 everywhere: one split
-  // some step of the range runs the group path (32 splits per KV group: too many to re-read in every wo workgroup):
-  // its merge is the separate launch, or - KH_FLAG_ATTN_MERGE_IN_LAUNCH - the last arriver's
-  if (pos_hi + 1 >= m->attn_t_long) return m->attn_merge_launch ? 4 : 0;
-  const int splits = attn_active_splits(pos_hi, m->attn_ns);
-  // k_wo_comb costs +1.1 us at 2 splits ... +3.3 at 16, the separate launch a flat ~2.5 (1.55 of launch floor + two
-  // L2 round trips): the former up to 7 splits, the latter from 8 on (profiles/r4_attn_merge_launch_ab.txt)
-  const int comb_max = m->attn_merge_launch && m->attn_merge_from - 1 < m->attn_defer_max ? m->attn_merge_from - 1
-                                                                                        : m->attn_defer_max;
-  if (m->attn_defer && splits <= comb_max) return 1;
-  if (m->attn_merge_launch) return 3;
+  if (pos_hi < KH_ATTN_MIN_TS) return 0;         // pos + 1 <= 256 everywhere: one split
+  if (pos_hi + 1 >= m->attn_t_long) return 0;    // some step runs the group path
+  if (m->attn_defer && attn_active_splits(pos_hi, m->attn_ns) <= m->attn_defer_max) return 1;
   // Variant 2: the merge stays in the attention launch, but every step of the range is below the group path's
   // threshold, so the launch uses the per-head-only instantiation.  The one that also carries the group path needs
   // 138+ registers (two K/V batches in flight for kv_mul heads): one 512-thread workgroup per CU, which cost the 512
-  // (head, split) workgroups at position 4094 +3.6 us per layer (profiles/r4_attn_pipe_ab.txt); per-head-only: 116.
+  // (head, split) workgroups at position 4094 +3.6 us per layer (profiles/r4_attn_pipe_ab.txt); per-head-only: 115.
   return m->attn_ns_g > 0 ? 2 : 0;
 }
 // one fused decode step = 5L + 2 launches.  ev (optional) receives an event after each launch.
