@@ -166,6 +166,8 @@ def lib() -> C.CDLL:
 
 def debug_set(key: str, value: Optional[str]) -> None:
     """Set (or with None: clear) one tuning / test hook of the library (kh_debug_set)."""
+    global _ENV_SEEN
+    _ENV_SEEN = None  # the table no longer mirrors os.environ: the next sync_env() walks it again
     check(lib().kh_debug_set(key.encode(), None if value is None else str(value).encode()), "kh_debug_set")
 
 
@@ -175,6 +177,7 @@ def debug_get(key: str) -> Optional[str]:
 
 
 _HOOK_PREFIXES = ("KH_SHAPE_", "KH_ATTN_", "KH_PG_", "KH_PREFILL")
+_ENV_SEEN = None  # the hook variables as of the last sync_env()
 
 
 def sync_env() -> None:
@@ -183,16 +186,20 @@ def sync_env() -> None:
     The library reads the environment once, when it is loaded; afterwards hooks change only through
     kh_debug_set.  The Python binding calls this before every entry point that reads a hook, so
     `os.environ[...] = ...` / `monkeypatch.setenv` keep working in tests and tools."""
+    global _ENV_SEEN
+    want = {k: v for k, v in os.environ.items() if k.startswith(_HOOK_PREFIXES)}
+    if want == _ENV_SEEN:  # nothing changed since the last call: no table walk per generate()
+        return
     L = lib()
     need = L.kh_debug_list(None, 0)
     buf = C.create_string_buffer(int(need))
     L.kh_debug_list(buf, need)
     have = {k for k in buf.value.decode().split("\n") if k.startswith(_HOOK_PREFIXES)}
-    want = {k: v for k, v in os.environ.items() if k.startswith(_HOOK_PREFIXES)}
     for k in have - set(want):
         L.kh_debug_set(k.encode(), None)
     for k, v in want.items():
         L.kh_debug_set(k.encode(), v.encode())
+    _ENV_SEEN = dict(want)
 
 
 def error_string(code: int) -> str:

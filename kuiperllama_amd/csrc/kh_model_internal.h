@@ -70,7 +70,8 @@ struct kh_model {
   size_t pg_ws_tok_bytes = 0;
   bool pf_ready = false, pg_ready = false;  // set when ALL prefill slabs exist (allocation can fail half-way)
   bool pg_launch_failed = false;
-  int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check)
+  int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check, final copy-out)
+  int32_t* h_forced_pin = nullptr; // pinned staging of d_forced [seq_cap + 1]: the upload needs no host sync
   int pin_cap = 0;
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   // launch geometry

@@ -354,6 +354,7 @@ extern "C" void kh_model_destroy(kh_model* m) {
   for (auto e : m->ev_chunk)
     if (e) (void)hipEventDestroy(e);
   if (m->h_words_pin) (void)hipHostFree(m->h_words_pin);
+  if (m->h_forced_pin) (void)hipHostFree(m->h_forced_pin);
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
                   m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
                   m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,

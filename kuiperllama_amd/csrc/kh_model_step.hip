@@ -467,9 +467,13 @@ int ensure_seq_cap(kh_model* m, int n) {
   if (n <= m->seq_cap) return KH_OK;
   if (m->d_forced) (void)hipFree(m->d_forced);
   if (m->d_words) (void)hipFree(m->d_words);
+  if (m->h_forced_pin) (void)hipHostFree(m->h_forced_pin);
   m->d_forced = m->d_words = nullptr;
+  m->h_forced_pin = nullptr;
   m->seq_cap = 0;
   int rc;
+  if (hipHostMalloc((void**)&m->h_forced_pin, sizeof(int32_t) * ((size_t)n + 1), hipHostMallocDefault) != hipSuccess)
+    return (int)hipErrorUnknown;
   if ((rc = dalloc(&m->d_forced, (size_t)n + 1)) != KH_OK) return rc;
   if ((rc = dalloc(&m->d_words, (size_t)n + 1)) != KH_OK) return rc;
   // forced[i] = -1 (0xFFFFFFFF): every position sampled, until a generate uploads its prompt
@@ -505,6 +509,10 @@ int step_graph_n(kh_model* m, int n_forced, int variant, int nsteps, hipGraphExe
   if (!sg.e) {
     const int rc = capture_steps(m, n_forced, nsteps, variant, &sg.g, &sg.e);
     if (rc != KH_OK) return rc;
+    // push the executable graph to the device now: otherwise its FIRST launch pays for it (a 20-step run behind a
+    // 5-step warm-up launched its 8-step graph for the first time inside the timed region: 1037-1046 tok/s by wall
+    // clock where repeated runs gave 1060)
+    (void)hipGraphUpload(sg.e, m->stream);
   }
   *out = sg.e;
   return KH_OK;
@@ -643,21 +651,42 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   if (exec != KH_EXEC_GRAPH && exec != KH_EXEC_FUSED) return KH_ERR_INVALID_ARG;
 
   if ((rc = ensure_seq_cap(m, total_steps)) != KH_OK) return rc;
-  // forced[i] = token fed at position i while inside the prompt, -1 afterwards
-  std::vector<int32_t> forced((size_t)m->seq_cap + 1, -1);
-  for (int i = 0; i < n_prompt && i <= m->seq_cap; ++i) forced[i] = h_prompt[i];
-  KH_CHECK_HIP(hipMemcpyAsync(m->d_forced, forced.data(), forced.size() * sizeof(int32_t),
-                              hipMemcpyHostToDevice, m->stream));
-  KH_CHECK_HIP(hipStreamSynchronize(m->stream));  // `forced` is a stack-lifetime staging buffer
+  // pinned mirror of the words, sized like the device buffers so that a longer run later does not re-allocate it (a
+  // hipHostMalloc inside the step loop's event bracket stalled the first 20-step run behind a 5-step one by 0.3 ms)
+  if ((rc = ensure_pinned_words(m, m->seq_cap)) != KH_OK) return rc;
+  // forced[i] = token fed at position i while inside the prompt, -1 afterwards.  Staged in the model's pinned
+  // buffer: the upload is ordered before the steps by the stream and needs no host-side wait (every generate ends
+  // with a stream sync, so the buffer is never refilled under a copy in flight); only the first total_steps + 1
+  // entries are read by this run
+  {
+    const int nf = total_steps + 1 <= m->seq_cap + 1 ? total_steps + 1 : m->seq_cap + 1;
+    for (int i = 0; i < nf; ++i) m->h_forced_pin[i] = i < n_prompt ? h_prompt[i] : -1;
+    KH_CHECK_HIP(hipMemcpyAsync(m->d_forced, m->h_forced_pin, (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice,
+                                m->stream));
+  }
   const int n_forced = m->seq_cap + 1;
   if (exec == KH_EXEC_GRAPH) {
     // all four graphs of variant 0 (1 / 2 / 4 / 8 steps) exist after the first generate of a model, whatever its
     // length (a warm-up run of 5 steps must leave the 8-step graph behind: capturing 656 nodes costs ~0.8 ms, which a
     // 20-step run would otherwise pay inside its timed loop); the other variants are captured when a run first
     // reaches position 256
+    // ... and each has been LAUNCHED once: the first launch of an instantiated graph costs ~0.1-0.3 ms on this
+    // runtime even after hipGraphUpload (a 20-step run behind a 5-step warm-up: 1012 tok/s, every later one 1028 on
+    // the same model instance).  The dry launches start at position 0 and write cache rows / words 0 .. 14 that this
+    // very call rewrites (generate always starts at position 0); skipped when the cache is shorter than that.
+    bool fresh[4] = {false, false, false, false};
     hipGraphExec_t ge = nullptr;
-    for (int n = 1; n <= KH_GRAPH_STEPS; n *= 2)
+    for (int n = 1, k = 0; n <= KH_GRAPH_STEPS; n *= 2, ++k) {
+      fresh[k] = m->sg[0][k].e == nullptr;
       if ((rc = step_graph_n(m, n_forced, 0, n, &ge)) != KH_OK) return rc;
+    }
+    if ((fresh[0] || fresh[1] || fresh[2] || fresh[3]) && c.cache_len >= 2 * KH_GRAPH_STEPS &&
+        m->seq_cap >= 2 * KH_GRAPH_STEPS) {
+      set_state(m, h_prompt[0], 0);
+      for (int k = 3; k >= 0; --k)
+        if (fresh[k]) KH_CHECK_HIP(hipGraphLaunch(m->sg[0][k].e, m->stream));
+      KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    }
   }
 
   // prompt phase: the tokens that are only fed (positions 0 .. n_prompt-2).  KH_PREFILL selects how:
@@ -710,16 +739,17 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     }
     KH_CHECK_HIP(hipEventRecord(m->ev1, m->stream));
     if ((rc = kh_launch_status()) != KH_OK) return rc;
-    KH_CHECK_HIP(hipMemcpyAsync(h_words, m->d_words, sizeof(int32_t) * total_steps,
+    // through the pinned mirror: a device-to-pageable copy is staged and synchronised by the runtime on top of ours
+    KH_CHECK_HIP(hipMemcpyAsync(m->h_words_pin, m->d_words, sizeof(int32_t) * total_steps,
                                 hipMemcpyDeviceToHost, m->stream));
     KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    memcpy(h_words, m->h_words_pin, sizeof(int32_t) * (size_t)total_steps);
     for (int i = 0; i < start; ++i) h_words[i] = h_prompt[i + 1];  // forced, main.cpp:36-38
   } else {
     // Stop-token check without a per-step host round trip: the words of every
     // chunk of steps are mirrored into pinned memory behind the chunk, and the host inspects
     // chunk k while chunk k+1 is already queued, so the GPU never waits for the check.  At
     // most two chunks of steps run past the stop token; their words are discarded.
-    if ((rc = ensure_pinned_words(m, total_steps)) != KH_OK) return rc;
     struct Chunk { int s0, n; };
     Chunk infl[2];
     int n_infl = 0, head = 0, launched = start, stop_at = -1;

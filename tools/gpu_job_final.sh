@@ -11,4 +11,5 @@ SECONDS=0
 timeout 900 python bench.py > $O/r4_bench.json 2> $O/r4_bench.err
 echo "bench rc=$? wall=${SECONDS}s" >> $O/r4_bench.err
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/r4_bench_steps20.json 2> $O/r4_bench_steps20.err
+timeout 300 python tools/gen_overhead.py 2>&1 | grep -v amdgpu > $O/r4_generate_overhead.txt
 tail -4 $O/r4_pytest_gpu.txt; tail -2 $O/r4_smoke.txt; grep -E "bench rc" $O/r4_bench.err; head -c 400 $O/r4_bench.json
