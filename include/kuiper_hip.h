@@ -258,6 +258,24 @@ int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t po
  * 64 (int8), int8 group size != 64. */
 int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
 
+/* Near-tie report for prompts that went through a prefill.  The token-by-token prompt phase and kh_model_prefill
+ * leave bit-identical K/V rows; kh_model_prefill_gemm (the default of kh_model_generate* from 16 fed-only tokens on)
+ * leaves them within fp32 round-off, so the greedy continuation is the token-by-token one unless two logits of a
+ * sampled step lie closer together than that round-off.  After every kh_model_generate* call whose prompt phase ran
+ * as a prefill, the logits of the FIRST sampled step (the one the whole prompt feeds; later steps inherit its choice)
+ * are kept on the device; this call returns their two largest entries.  top1_id is the token that step sampled;
+ * top1 - top2 is the margin to compare with the tolerance the caller cares about (the parity tests use 4e-5 for
+ * fp32, 1e-4 for int8 weights: tests/test_model_gpu.py).  prefill_mode: 1 = kh_model_prefill (bit-identical rows),
+ * 2 = kh_model_prefill_gemm.  KH_ERR_UNSUPPORTED when the last generate had no prefill phase (prompts of fewer than
+ * 3 tokens, KH_PREFILL=0, unsupported geometry): its tokens are the token-by-token ones by construction. */
+typedef struct kh_first_sample {
+  int32_t pos;           /* position of the first sampled step = n_prompt - 1 */
+  int32_t prefill_mode;  /* 1 = B-token VALU prefill (bit-identical), 2 = MFMA GEMM prefill (fp32 tolerance) */
+  int32_t top1_id, top2_id;
+  float top1, top2;      /* the two largest logits of that step; ties -> lowest index first, like the sampler */
+} kh_first_sample;
+int kh_model_first_sample(kh_model* m, kh_first_sample* out);
+
 /* Launch plans, host-only (no device is touched; for tools and the CPU test-suite).
  * kh_plan_decode_shapes: {split, u, grid, wg} of the five GEMV kernels of a decode step (qkv, wo, ffn13, w2,
  * cls) for a geometry - what kh_model_create_* configures (env KH_SHAPE_* overrides included).

@@ -26,7 +26,7 @@ EXPORTS = [
     "kh_spm_bos_id", "kh_spm_eos_id", "kh_spm_unk_id", "kh_spm_encode", "kh_spm_decode",
     "kh_bpe_create_from_file", "kh_bpe_create_from_memory", "kh_bpe_destroy", "kh_bpe_vocab_size",
     "kh_bpe_bos_id", "kh_bpe_eos_id", "kh_bpe_stop_id", "kh_bpe_encode", "kh_bpe_decode",
-    "kh_model_generate", "kh_model_generate_until", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
+    "kh_model_generate", "kh_model_generate_until", "kh_model_first_sample", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
     "kh_plan_decode_shapes", "kh_plan_prefill_shape",
     "kh_debug_set", "kh_debug_get", "kh_debug_list",
 ]
@@ -47,6 +47,11 @@ class ModelOpts(C.Structure):
     _fields_ = [("family", C.c_int32), ("is_quant", C.c_int32), ("rope_mode", C.c_int32),
                 ("rope_theta", C.c_float), ("rms_eps", C.c_float), ("max_seq_len", C.c_int32),
                 ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+class FirstSample(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("prefill_mode", C.c_int32), ("top1_id", C.c_int32), ("top2_id", C.c_int32),
+                ("top1", C.c_float), ("top2", C.c_float)]
 
 
 class Config(C.Structure):
@@ -121,6 +126,7 @@ def lib() -> C.CDLL:
                                     C.POINTER(_i32), C.POINTER(_f32)]
     L.kh_model_generate_until.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),
                                           _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32)]
+    L.kh_model_first_sample.argtypes = [_vp, C.POINTER(FirstSample)]
     L.kh_model_time_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32)]
     L.kh_plan_decode_shapes.argtypes = [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_plan_prefill_shape.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]

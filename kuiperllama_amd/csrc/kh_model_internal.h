@@ -72,6 +72,10 @@ struct kh_model {
   bool pg_launch_failed = false;
   int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check, final copy-out)
   int32_t* h_forced_pin = nullptr; // pinned staging of d_forced [seq_cap + 1]: the upload needs no host sync
+  // near-tie report (kh_model_first_sample): logits of the first sampled step of the last generate with a prefill
+  float* first_logits = nullptr;  // [vocab], allocated on first use
+  int first_pos = -1;             // -1: the last generate had no prefill phase
+  int first_mode = 0;             // 1 = kh_model_prefill, 2 = kh_model_prefill_gemm
   int pin_cap = 0;
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   // launch geometry

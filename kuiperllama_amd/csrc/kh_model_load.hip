@@ -355,6 +355,7 @@ extern "C" void kh_model_destroy(kh_model* m) {
     if (e) (void)hipEventDestroy(e);
   if (m->h_words_pin) (void)hipHostFree(m->h_words_pin);
   if (m->h_forced_pin) (void)hipHostFree(m->h_forced_pin);
+  if (m->first_logits) (void)hipFree(m->first_logits);
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
                   m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
                   m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
@@ -470,6 +471,32 @@ extern "C" int kh_model_get_logits(kh_model* m, float* h_logits) {
   KH_CHECK_HIP(hipMemcpyAsync(h_logits, m->logits, sizeof(float) * m->cfg.vocab_size,
                               hipMemcpyDeviceToHost, m->stream));
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  return KH_OK;
+}
+extern "C" int kh_model_first_sample(kh_model* m, kh_first_sample* out) {
+  if (!m || !out) return KH_ERR_INVALID_ARG;
+  if (m->first_pos < 0 || !m->first_logits) return KH_ERR_UNSUPPORTED;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  const int V = m->cfg.vocab_size;
+  std::vector<float> h((size_t)V);
+  KH_CHECK_HIP(hipMemcpyAsync(h.data(), m->first_logits, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, m->stream));
+  KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  // two largest, ties -> lowest index first (the sampler's rule, argmax_sampler.cpp:7)
+  int i1 = 0, i2 = -1;
+  for (int i = 1; i < V; ++i) {
+    if (h[i] > h[i1]) {
+      i2 = i1;
+      i1 = i;
+    } else if (i2 < 0 || h[i] > h[i2]) {
+      i2 = i;
+    }
+  }
+  out->pos = m->first_pos;
+  out->prefill_mode = m->first_mode;
+  out->top1_id = i1;
+  out->top2_id = i2;
+  out->top1 = h[i1];
+  out->top2 = i2 >= 0 ? h[i2] : h[i1];
   return KH_OK;
 }
 extern "C" int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache) {

@@ -710,10 +710,19 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     if (want_gemm && pg_supported(m)) {
       if ((rc = kh_model_prefill_gemm(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
       start = n_prompt - 1;
+      m->first_mode = 2;
     } else if (want_gemv && prefill_supported(m)) {
       if ((rc = kh_model_prefill(m, h_prompt, n_prompt - 1, 0)) != KH_OK) return rc;
       start = n_prompt - 1;
+      m->first_mode = 1;
     }
+  }
+  // near-tie report (kh_model_first_sample): with a prefill the first sampled step runs on its own and its logits
+  // are put aside before the next step overwrites them
+  m->first_pos = -1;
+  if (start > 0) {
+    if (!m->first_logits) KH_CHECK_HIP(hipMalloc(&m->first_logits, sizeof(float) * (size_t)c.vocab_size));
+    m->first_pos = start;
   }
   set_state(m, h_prompt[start], start);
   auto launch_chunk = [&](int s) -> int {  // enqueue the next 1 or KH_GRAPH_STEPS steps (positions s ..)
@@ -722,12 +731,21 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
       // the 20-step form of the bench ran 8 + 8 + 1 + 1 + 1 + 1 and lost 0.3 % to it; now 8 + 8 + 4)
       int n = KH_GRAPH_STEPS;
       while (n > total_steps - s) n >>= 1;
+      const bool keep = s == start && start > 0;  // first sampled step behind a prefill: alone, logits kept
+      if (keep) n = 1;
       hipGraphExec_t ge = nullptr;
       if (step_graph_n(m, n_forced, step_variant(m, s, s + n - 1), n, &ge) != KH_OK) return -1;
       if (hipGraphLaunch(ge, m->stream) != hipSuccess) return -1;
+      if (keep && hipMemcpyAsync(m->first_logits, m->logits, sizeof(float) * (size_t)c.vocab_size,
+                                 hipMemcpyDeviceToDevice, m->stream) != hipSuccess)
+        return -1;
       return n;
     }
     launch_step_fused(m, 1, n_forced, nullptr, step_variant(m, s, s));
+    if (s == start && start > 0 &&
+        hipMemcpyAsync(m->first_logits, m->logits, sizeof(float) * (size_t)c.vocab_size, hipMemcpyDeviceToDevice,
+                       m->stream) != hipSuccess)
+      return -1;
     return 1;
   };
   int n_out = total_steps;

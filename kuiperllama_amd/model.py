@@ -159,6 +159,18 @@ class KuiperModel:
                    "kh_model_generate_until")
         return list(words[: n.value]), float(ms.value)
 
+    def first_sample(self) -> Optional[dict]:
+        """Near-tie report of the last generate() whose prompt ran as a prefill: the two largest logits of its
+        first sampled step (kh_model_first_sample).  None when that generate had no prefill phase."""
+        fs = _ffi.FirstSample()
+        rc = _ffi.lib().kh_model_first_sample(self._h, C.byref(fs))
+        if rc == -2:  # KH_ERR_UNSUPPORTED: no prefill phase
+            return None
+        _ffi.check(rc, "kh_model_first_sample")
+        return {"pos": fs.pos, "prefill_mode": {1: "gemv", 2: "gemm"}.get(fs.prefill_mode, str(fs.prefill_mode)),
+                "top1_id": fs.top1_id, "top2_id": fs.top2_id, "top1": float(fs.top1), "top2": float(fs.top2),
+                "margin": float(fs.top1) - float(fs.top2)}
+
     def prefill(self, tokens: Sequence[int], pos0: int = 0) -> None:
         """Forward of `tokens` at positions pos0.. without logits, 8 (fp32) / 4 (int8) tokens per
         weight pass on the VALU; the K/V rows are bit-identical to token-by-token

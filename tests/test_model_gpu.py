@@ -747,9 +747,27 @@ def test_generate_long_prompt_takes_gemm_prefill(gpu, oracle, name, monkeypatch)
     got, _ = m.generate(prompt, steps)
     if got != want:
         _fail_with_margin(oracle, img_h, spec, prompt, got, want)
+    # near-tie report of the tolerance-parity path (kh_model_first_sample): the two largest logits of the first
+    # sampled step = the oracle's at that position, top-1 = the token that step sampled
+    om = oracle.OracleModel.from_spec(img_h, spec)
+    for pos, tok in enumerate(prompt):
+        om.forward(tok, pos)
+    ref = om.logits().copy()
+    order = np.lexsort((np.arange(ref.size), -ref))  # descending, ties -> lowest index
+    fs = m.first_sample()
+    assert fs is not None and fs["prefill_mode"] == "gemm" and fs["pos"] == len(prompt) - 1
+    assert fs["top1_id"] == got[len(prompt) - 1] == int(order[0]) and fs["top2_id"] == int(order[1])
+    assert abs(fs["top1"] - ref[order[0]]) <= _atol(spec) and abs(fs["top2"] - ref[order[1]]) <= _atol(spec)
+    assert abs(fs["margin"] - (ref[order[0]] - ref[order[1]])) <= 2 * _atol(spec)
     for mode in ("gemm", "gemv", "0", "token"):
         monkeypatch.setenv("KH_PREFILL", mode)
         assert m.generate(prompt, steps)[0] == want, mode
+        fs2 = m.first_sample()
+        if mode in ("0", "token"):
+            assert fs2 is None  # no prefill phase: the tokens are the token-by-token ones by construction
+        else:
+            assert fs2["prefill_mode"] == mode and fs2["top1_id"] == fs["top1_id"]
+            assert abs(fs2["margin"] - fs["margin"]) <= 2 * _atol(spec)
     # an unknown value is an error, not a silent choice of path (it used to select "gemv")
     from kuiperllama_amd import _ffi
     monkeypatch.setenv("KH_PREFILL", "1")
