@@ -219,8 +219,13 @@ def load_traffic(kernel_key):
             doc = json.load(f)
         ent = doc.get(kernel_key)
         meta = doc.get("_meta", {})
+        from kuiperllama_amd.build import kernel_sources_sha1
         src = {"file": TRAFFIC_FILE, "measured_in_this_run": False,
                "collected_on_commit": meta.get("commit"), "collected_by": meta.get("command"),
+               # the device-code headers hashed at collection time against the ones this run was built from: a kernel
+               # change after the PMC passes shows here instead of silently keeping a stale ratio
+               "kernel_sources_unchanged": (meta.get("kernel_sources_sha1") == kernel_sources_sha1()
+                                            if meta.get("kernel_sources_sha1") else None),
                "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024"}
         return (float(ent["hbm_bytes"]) if ent else None), src
     except Exception:

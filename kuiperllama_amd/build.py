@@ -153,3 +153,19 @@ def build_ref_model() -> str | None:
     subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
                            "ref_model", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
     return REF_MODEL_BIN
+
+
+def kernel_sources_sha1() -> str:
+    """sha1 over the device-code headers of the decode / prefill kernels (csrc/kh_*.h except the host-only
+    kh_model_internal.h), in name order.  profiles/pmc_traffic.json is stamped with it when the PMC passes are
+    collected; bench.py recomputes it, so a kernel change after the collection shows in the record
+    (roofline.traffic_source.kernel_sources_unchanged) instead of silently keeping a stale traffic ratio."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("kh_") and f.endswith(".h") and f != "kh_model_internal.h":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+

@@ -52,3 +52,16 @@ def test_algorithmic_bytes_match_survey_table():
     assert bench.ffn13_bytes(p["llama3.2-1b"]) == 2 * 8192 * 2048 * 4 + 2 * 2048 * 4 + 8192 * 4
     n = 2 * 11008 * 4096
     assert bench.ffn13_bytes(p["llama2-7b-int8"]) == n + n // 64 * 4 + 2 * 4096 * 4 + 11008 * 4
+
+
+def test_traffic_provenance_names_the_kernel_sources():
+    """roofline.traffic is read from profiles/pmc_traffic.json (separate PMC passes).  The file carries the sha1 of
+    the device-code headers it was collected on and bench.py compares it with the tree it runs from, so a kernel change
+    after the collection shows in the record (kernel_sources_unchanged: false) instead of keeping a stale ratio."""
+    import bench
+    from kuiperllama_amd.build import kernel_sources_sha1
+    tr, src = bench.load_traffic("llama3.2-1b:ffn13")
+    assert tr and tr > 1e8
+    assert src["collected_on_commit"] and src["kernel_sources_unchanged"] in (True, False)
+    assert len(kernel_sources_sha1()) == 40
+

@@ -16,6 +16,7 @@ import argparse
 import csv
 import json
 import os
+import sys
 import re
 import sqlite3
 
@@ -99,7 +100,10 @@ def main():
             v["hbm_bytes"] = v.get("read_bytes", 0.0) + v.get("write_bytes_uncalibrated", 0.0)
             v["note"] = "per launch; read side = FETCH_SIZE KiB x1024 x2 (gfx950 correction)"
             old[k] = v
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from kuiperllama_amd.build import kernel_sources_sha1
         old["_meta"] = {"commit": a.commit or None, "command": a.command,
+                        "kernel_sources_sha1": kernel_sources_sha1(),
                         "note": "HBM bytes per launch from separate rocprofv3 PMC passes; bench.py reads "
                                 "roofline.traffic from this file (it is NOT measured inside a bench run)"}
         json.dump(old, open(tp, "w"), indent=1, sort_keys=True)
