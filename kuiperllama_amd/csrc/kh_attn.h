@@ -212,6 +212,9 @@ __host__ __device__ static inline int attn_split_len(int nT, int NS) {
   return TS < KH_ATTN_MIN_TS ? KH_ATTN_MIN_TS : TS;
 }
 __host__ __device__ static inline int attn_active_splits(int pos, int NS) {
+  // every split is KH_ATTN_MIN_TS long up to NS of them: a shift, no division (this runs on the device too, between
+  // the arrival of the position and the first address of k_wo_comb's staging)
+  if (pos + 1 <= NS * KH_ATTN_MIN_TS) return (pos + KH_ATTN_MIN_TS) / KH_ATTN_MIN_TS;
   const int TS = attn_split_len(pos + 1, NS);
   return (pos + 1 + TS - 1) / TS;
 }
@@ -427,8 +430,16 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
   if (NSW <= 0) NSW = NS;  // slot stride of the workspace (>= NS)
   const int tid = threadIdx.x;
   const int nT = pos + 1;
-  const int TS = attn_split_len(nT, NS);
-  const int nact = (nT + TS - 1) / TS;  // uniform over the grid
+  // up to NS * 256 timesteps every split is 256 long (attn_split_len's minimum): no division between the arrival of
+  // the position and the first address; longer contexts take the general form (same values)
+  int TS, nact;
+  if (nT <= NS * KH_ATTN_MIN_TS) {
+    TS = KH_ATTN_MIN_TS;
+    nact = (nT + KH_ATTN_MIN_TS - 1) / KH_ATTN_MIN_TS;  // a shift
+  } else {
+    TS = attn_split_len(nT, NS);
+    nact = (nT + TS - 1) / TS;  // uniform over the grid
+  }
   if (s >= nact) return false;
   const int t_begin = s * TS;
   const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
@@ -688,15 +699,25 @@ struct KhAttnArgs {
   // out rows tok_stride floats apart, its split workspace ws_tok_bytes apart (decode: y = 1)
   int tok_stride;
   size_t ws_tok_bytes;
+  int kvh_shift, kvm_shift;  // log2 of kv_heads / kv_mul when they are powers of two, else -1 (set by launch_attn_decode)
 };
 
 // per-head path: block -> (kv group g, head-in-group j, split s).  Blocks are placed on XCD
 // b % 8, so with g = b % kv_heads the kv_mul heads that share K/V rows share an XCD's L2.
 template <int G>
 __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem, int b, int pos) {
-  const int g = b % a.kv_heads;
-  const int j = (b / a.kv_heads) % a.kv_mul;
-  const int s = b / (a.kv_heads * a.kv_mul);
+  // power-of-two head counts (every Llama-family config): shifts instead of three integer divisions (~40
+  // instructions each, in front of the first address of a launch whose whole body is ~2 us)
+  int g, j, s;
+  if (a.kvh_shift >= 0 && a.kvm_shift >= 0) {  // uniform
+    g = b & (a.kv_heads - 1);
+    j = (b >> a.kvh_shift) & (a.kv_mul - 1);
+    s = b >> (a.kvh_shift + a.kvm_shift);
+  } else {
+    g = b % a.kv_heads;
+    j = (b / a.kv_heads) % a.kv_mul;
+    s = b / (a.kv_heads * a.kv_mul);
+  }
   const int h = g * a.kv_mul + j;
   const size_t head_off = (size_t)g * a.head_size;
   attn_head_decode_fast<G>(
@@ -811,6 +832,13 @@ static inline int attn_tlong_hook() {
 static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStream_t s,
                                       int ntok = 1, int pos_hi = -1) {
   const int G = attn_lanes(a.head_size);
+  auto log2_or_neg = [](int v) {
+    int sh = 0;
+    while ((1 << sh) < v) ++sh;
+    return (1 << sh) == v ? sh : -1;
+  };
+  a.kvh_shift = log2_or_neg(a.kv_heads);
+  a.kvm_shift = log2_or_neg(a.kv_mul);
   // host-positioned launch whose positions all stay below the group path's threshold: the per-head-only
   // instantiation (fewer registers: two 512-thread workgroups per CU instead of one, which matters when 16 splits
   // x 32 heads are in flight).  Device-positioned callers clear nsplit_g themselves when they know the range.
