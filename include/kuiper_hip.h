@@ -283,6 +283,12 @@ int kh_model_first_sample(kh_model* m, kh_first_sample* out);
  * pass (epi 0 = QKV, 1 = residual GEMM wo / w2, 2 = SwiGLU pair; csrc/kh_model_prefill.hip::pg_shape). */
 int kh_plan_decode_shapes(int32_t dim, int32_t hidden_dim, int32_t kv_dim, int32_t vocab_size,
                           int32_t is_quant, int32_t* out20);
+/* kh_plan_attention: the decode-attention geometry of kh_mha_decode_f32 / the fused step for a cache of seq_len rows:
+ * out8 = {time splits per head, splits per KV group (0: no group path), workspace slot stride, first pos + 1 of the
+ * group path, path taken at `pos` (0 per-head, 1 group), active splits at `pos`, timesteps per split at `pos`,
+ * workgroups that own timesteps at `pos`} (KH_ATTN_TLONG honoured). */
+int kh_plan_attention(int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t seq_len, int32_t pos,
+                      int32_t* out8);
 int kh_plan_prefill_shape(int32_t epi, int32_t T, int32_t rows, int32_t K, int32_t is_quant,
                           int32_t r2_ok, int32_t* out7);
 

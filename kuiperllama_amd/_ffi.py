@@ -27,7 +27,7 @@ EXPORTS = [
     "kh_bpe_create_from_file", "kh_bpe_create_from_memory", "kh_bpe_destroy", "kh_bpe_vocab_size",
     "kh_bpe_bos_id", "kh_bpe_eos_id", "kh_bpe_stop_id", "kh_bpe_encode", "kh_bpe_decode",
     "kh_model_generate", "kh_model_generate_until", "kh_model_first_sample", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
-    "kh_plan_decode_shapes", "kh_plan_prefill_shape",
+    "kh_plan_decode_shapes", "kh_plan_prefill_shape", "kh_plan_attention",
     "kh_debug_set", "kh_debug_get", "kh_debug_list",
 ]
 
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
     L.kh_model_time_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32)]
     L.kh_plan_decode_shapes.argtypes = [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_plan_prefill_shape.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
+    L.kh_plan_attention.argtypes = [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_spm_create_from_file.argtypes = [C.c_char_p, C.POINTER(_vp)]
     L.kh_spm_create_from_memory.argtypes = [_vp, C.c_int64, C.POINTER(_vp)]
     L.kh_spm_destroy.argtypes = [_vp]
@@ -226,6 +227,17 @@ def plan_decode_shapes(dim: int, hidden_dim: int, kv_dim: int, vocab_size: int, 
         raise KhError(rc, "kh_plan_decode_shapes")
     names = ("qkv", "wo", "ffn13", "w2", "cls")
     return {n: dict(zip(("split", "u", "grid", "wg"), out[4 * i:4 * i + 4])) for i, n in enumerate(names)}
+
+
+def plan_attention(head_num: int, kv_mul: int, head_size: int, seq_len: int, pos: int) -> dict:
+    """Decode-attention geometry for a cache of seq_len rows at position pos (host-only, kh_plan_attention)."""
+    sync_env()
+    out = (_i32 * 8)()
+    rc = lib().kh_plan_attention(head_num, kv_mul, head_size, seq_len, pos, out)
+    if rc != 0:
+        raise KhError(rc, "kh_plan_attention")
+    return dict(zip(("ns", "ns_g", "stride", "t_long", "group_path", "active_splits", "split_len", "workgroups"),
+                    list(out)))
 
 
 def plan_prefill_shape(epi: str, T: int, rows: int, K: int, quant: bool, r2_ok: bool = True) -> dict:

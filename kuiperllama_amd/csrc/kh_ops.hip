@@ -546,6 +546,29 @@ extern "C" int64_t kh_mha_decode_workspace_bytes(int32_t head_num, int32_t head_
     }
   return best;
 }
+// Host-only view of the decode-attention geometry (tools, CPU test-suite): out8 = {ns, ns_g, slot stride, t_long,
+// path at `pos` (0 = per-head workgroups, 1 = GQA group path), active splits at `pos`, timesteps per split at `pos`,
+// workgroups that own timesteps at `pos`}.
+extern "C" int kh_plan_attention(int32_t head_num, int32_t kv_mul, int32_t head_size, int32_t seq_len, int32_t pos,
+                                 int32_t* out8) {
+  if (!out8 || head_num <= 0 || kv_mul <= 0 || head_num % kv_mul || head_size <= 0 || seq_len <= 0 || pos < 0 ||
+      pos >= seq_len)
+    return KH_ERR_INVALID_ARG;
+  int ns, ns_g, stride, tl;
+  mha_decode_geometry(head_num, kv_mul, head_size, seq_len, &ns, &ns_g, &stride, &tl);
+  const bool grp = ns_g > 0 && pos + 1 >= tl;
+  const int NS = grp ? ns_g : ns;
+  const int nact = attn_active_splits(pos, NS);
+  out8[0] = ns;
+  out8[1] = ns_g;
+  out8[2] = stride;
+  out8[3] = tl;
+  out8[4] = grp ? 1 : 0;
+  out8[5] = nact;
+  out8[6] = attn_split_len(pos + 1, NS);
+  out8[7] = (grp ? head_num / kv_mul : head_num) * nact;
+  return KH_OK;
+}
 extern "C" int kh_mha_decode_f32(const int32_t* d_pos, int32_t pos, int32_t head_num,
                                  int32_t layer_index, int32_t seq_len, int32_t kv_dim,
                                  int32_t kv_mul, int32_t head_size, float* mha_out, const float* q,

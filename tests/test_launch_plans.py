@@ -102,3 +102,39 @@ def test_prefill_plan_documented_shapes(monkeypatch):
         _ffi.plan_prefill_shape("qkv", 513, 3072, 2048, False, True)
     with pytest.raises(_ffi.KhError):
         _ffi.plan_prefill_shape("qkv", 128, 3072, 2040, False, True)
+
+
+def test_attention_plan_and_split_geometry(monkeypatch):
+    """The decode-attention geometry (kh_attn.h::attn_plan / attn_split_len / attn_active_splits - host AND device
+    code) through the host-only kh_plan_attention: the Llama-3.2-1B, Qwen2.5-0.5B, Llama-2-7B and tiny-head plans, the
+    per-head / group switch, and the split arithmetic at EVERY position of a long cache against its definition
+    (split length = ceil(timesteps / splits) rounded up to 64, at least 256; active = ceil(timesteps / length)) -
+    the device takes a division-free shortcut for timesteps <= 256 * splits that must give the same values."""
+    from kuiperllama_amd import _ffi
+    monkeypatch.delenv("KH_ATTN_TLONG", raising=False)
+    a = _ffi.plan_attention(32, 4, 64, 131072, 63)          # Llama-3.2-1B
+    assert (a["ns"], a["ns_g"], a["stride"], a["t_long"]) == (16, 32, 32, 4096)
+    assert (a["group_path"], a["active_splits"], a["split_len"], a["workgroups"]) == (0, 1, 256, 32)
+    assert _ffi.plan_attention(32, 4, 64, 131072, 4094)["workgroups"] == 32 * 16
+    b = _ffi.plan_attention(32, 4, 64, 131072, 4095)        # first position of the group path
+    assert (b["group_path"], b["active_splits"], b["workgroups"]) == (1, 16, 8 * 16)
+    assert _ffi.plan_attention(32, 4, 64, 131072, 131071)["workgroups"] == 8 * 32
+    q = _ffi.plan_attention(14, 7, 64, 32768, 32767)        # Qwen2.5-0.5B: 2 KV heads cannot fill the chip with groups
+    assert q["ns_g"] == 0 and q["group_path"] == 0 and q["active_splits"] == 16 and q["split_len"] == 2048
+    assert _ffi.plan_attention(32, 1, 128, 4096, 4095)["ns_g"] == 0   # MHA: no group path
+    assert _ffi.plan_attention(6, 1, 32, 256, 255)["ns"] == 1          # head size <= 32: generic kernel, no splits
+    monkeypatch.setenv("KH_ATTN_TLONG", "300")               # the hook moves the switch point
+    assert _ffi.plan_attention(32, 4, 64, 3000, 299)["group_path"] == 1
+    assert _ffi.plan_attention(32, 4, 64, 3000, 298)["group_path"] == 0
+    monkeypatch.delenv("KH_ATTN_TLONG")
+    for seq, heads, kvm in ((9000, 8, 1), (131072, 32, 4)):
+        ns = _ffi.plan_attention(heads, kvm, 64, seq, 0)["ns"]
+        step = 1 if seq < 20000 else 37
+        for pos in list(range(0, seq, step)) + [seq - 1]:
+            p = _ffi.plan_attention(heads, kvm, 64, seq, pos)
+            n = p["ns_g"] if p["group_path"] else ns
+            nt = pos + 1
+            want_len = max(256, (-(-nt // n) + 63) // 64 * 64)
+            assert p["split_len"] == want_len and p["active_splits"] == -(-nt // want_len), (seq, pos, p)
+            assert p["active_splits"] <= n
+
