@@ -283,6 +283,11 @@ int kh_model_first_sample(kh_model* m, kh_first_sample* out);
  * pass (epi 0 = QKV, 1 = residual GEMM wo / w2, 2 = SwiGLU pair; csrc/kh_model_prefill.hip::pg_shape). */
 int kh_plan_decode_shapes(int32_t dim, int32_t hidden_dim, int32_t kv_dim, int32_t vocab_size,
                           int32_t is_quant, int32_t* out20);
+/* kh_plan_decode_ring: out4 = {ffn13 ring slots per wave, ffn13 workgroups, cls ring slots, cls workgroups} - which
+ * int8 GEMVs of a decode step run on the LDS-DMA ring kernels (csrc/kh_fused_ring.h; 0 slots = the register-tile
+ * kernel of kh_plan_decode_shapes) and with how many 256-thread workgroups.  Hook KH_RING=0 turns them off. */
+int kh_plan_decode_ring(int32_t dim, int32_t hidden_dim, int32_t vocab_size, int32_t is_quant, int32_t group_size,
+                        int32_t* out4);
 /* kh_plan_attention: the decode-attention geometry of kh_mha_decode_f32 / the fused step for a cache of seq_len rows:
  * out8 = {time splits per head, splits per KV group (0: no group path), workspace slot stride, first pos + 1 of the
  * group path, path taken at `pos` (0 per-head, 1 group), active splits at `pos`, timesteps per split at `pos`,
@@ -292,7 +297,7 @@ int kh_plan_attention(int32_t head_num, int32_t kv_mul, int32_t head_size, int32
 int kh_plan_prefill_shape(int32_t epi, int32_t T, int32_t rows, int32_t K, int32_t is_quant,
                           int32_t r2_ok, int32_t* out7);
 
-/* Tuning / test hooks.  Every hook the library honours (KH_SHAPE_<QKV|WO|FFN|W2|CLS>, KH_ATTN_WG,
+/* Tuning / test hooks.  Every hook the library honours (KH_SHAPE_<QKV|WO|FFN|W2|CLS>, KH_RING, KH_ATTN_WG,
  * KH_ATTN_TLONG, KH_ATTN_DEFER (0 = never merge time splits in the wo kernel), KH_ATTN_DEFER_MAX (active splits up to
  * which it does), KH_PREFILL, KH_PG_<CHUNK|SHAPE_*|SOLO|KZ|ATTN|ATTN_QT|ROPE_FUSE|DEBUG>,
  * KH_SHAPE_DEBUG) lives in ONE process-wide key -> value table, seeded once from the KH_* variables of

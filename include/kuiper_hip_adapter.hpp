@@ -25,6 +25,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "kuiper_hip.h"
 
@@ -52,9 +54,58 @@ struct Flavor {
   float rms_eps = 1e-5f;
   float rope_theta = 10000.0f;
 };
+// The process default - what the reference fixes at compile time.
 inline Flavor& flavor() {
   static Flavor f;
   return f;
+}
+// Per-stream flavours, so that a Llama and a Qwen model can live in one process (the reference cannot: one
+// build, one #ifdef).  Every model object of the reference owns a stream (llama3.cpp:117-125) and passes it to
+// every kernel; RMSNorm / RoPE / the sin-cos table look the flavour up by that stream and fall back to the
+// process default.  sin_cos_cache_calc - the first kernel Model::init issues on its stream - BINDS the stream to
+// the default current at that moment: set flavor(), call model.init(), and the model keeps that flavour
+// whatever flavor() is changed to for the next model.  bind_flavor / unbind_flavor do the same explicitly.
+namespace detail {
+struct BoundFlavor {
+  void* stream;
+  Flavor f;
+};
+inline std::vector<BoundFlavor>& bound_flavors() {
+  static std::vector<BoundFlavor> v;
+  return v;
+}
+inline std::mutex& bound_flavors_mu() {
+  static std::mutex m;
+  return m;
+}
+}  // namespace detail
+inline void bind_flavor(void* stream, const Flavor& f) {
+  if (!stream) return;  // the null stream always follows the process default
+  std::lock_guard<std::mutex> g(detail::bound_flavors_mu());
+  for (auto& b : detail::bound_flavors())
+    if (b.stream == stream) {
+      b.f = f;
+      return;
+    }
+  detail::bound_flavors().push_back({stream, f});
+}
+inline void unbind_flavor(void* stream) {  // call when the stream is destroyed (handles are reused)
+  std::lock_guard<std::mutex> g(detail::bound_flavors_mu());
+  auto& v = detail::bound_flavors();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].stream == stream) {
+      v[i] = v.back();
+      v.pop_back();
+      return;
+    }
+}
+inline Flavor flavor_of(void* stream) {
+  if (stream) {
+    std::lock_guard<std::mutex> g(detail::bound_flavors_mu());
+    for (const auto& b : detail::bound_flavors())
+      if (b.stream == stream) return b.f;
+  }
+  return flavor();
 }
 
 // CudaConfig twin (kuiper/include/base/cuda_config.h:6-13): only the stream is used.
@@ -142,7 +193,7 @@ struct Kernels {
   static void rmsnorm(const Tensor& input, const Tensor& weight, const Tensor& output,
                       void* stream) {
     check(kh_rmsnorm_f32(input.template ptr<float>(), weight.template ptr<float>(),
-                         mut<float>(output), (int32_t)input.size(), flavor().rms_eps, stream),
+                         mut<float>(output), (int32_t)input.size(), flavor_of(stream).rms_eps, stream),
           "kh_rmsnorm_f32");
   }
   // RoPEKernel (kernels_interface.h:33-36): input_pos is a HOST int32 tensor in the reference
@@ -153,15 +204,18 @@ struct Kernels {
     const int32_t pos = *input_pos.template ptr<int32_t>();
     check(kh_rope_f32(dim, kv_dim, head_size, mut<float>(input_q), mut<float>(input_k), nullptr,
                       pos, sin_cache.template ptr<float>(), cos_cache.template ptr<float>(),
-                      flavor().rope_mode, stream),
+                      flavor_of(stream).rope_mode, stream),
           "kh_rope_f32");
   }
   // sin_cos_cache_calc_cu (cuda/rope_kernel.cuh:9-10); Stream = cudaStream_t in the reference.
-  // theta is an #ifdef there (cuda/rope_kernel.cu:124-151), flavor().rope_theta here.
+  // theta is an #ifdef there (cuda/rope_kernel.cu:124-151), the flavour's rope_theta here.  Model::init calls
+  // this once, on the model's own stream, before any other kernel: the stream is bound to the process default
+  // of this moment (see bind_flavor), which is what makes a second model with another flavour possible.
   template <class Stream>
   static void sin_cos_cache_calc(int head_size, int max_seq_len, const Tensor& sin_cache,
                                  const Tensor& cos_cache, Stream stream) {
-    check(kh_sincos_cache_f32(head_size, max_seq_len, flavor().rope_theta, mut<float>(sin_cache),
+    bind_flavor((void*)stream, flavor());
+    check(kh_sincos_cache_f32(head_size, max_seq_len, flavor_of((void*)stream).rope_theta, mut<float>(sin_cache),
                               mut<float>(cos_cache), (void*)stream),
           "kh_sincos_cache_f32");
   }

@@ -27,7 +27,7 @@ EXPORTS = [
     "kh_bpe_create_from_file", "kh_bpe_create_from_memory", "kh_bpe_destroy", "kh_bpe_vocab_size",
     "kh_bpe_bos_id", "kh_bpe_eos_id", "kh_bpe_stop_id", "kh_bpe_encode", "kh_bpe_decode",
     "kh_model_generate", "kh_model_generate_until", "kh_model_first_sample", "kh_model_time_step", "kh_model_prefill", "kh_model_prefill_gemm", "kh_model_time_prefill", "kh_model_profile_kernel", "kh_model_profile_step", "kh_kclass_name",
-    "kh_plan_decode_shapes", "kh_plan_prefill_shape", "kh_plan_attention",
+    "kh_plan_decode_shapes", "kh_plan_decode_ring", "kh_plan_prefill_shape", "kh_plan_attention",
     "kh_debug_set", "kh_debug_get", "kh_debug_list",
 ]
 
@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
     L.kh_model_first_sample.argtypes = [_vp, C.POINTER(FirstSample)]
     L.kh_model_time_step.argtypes = [_vp, _i32, _i32, C.POINTER(_f32)]
     L.kh_plan_decode_shapes.argtypes = [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
+    L.kh_plan_decode_ring.argtypes = [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_plan_prefill_shape.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_plan_attention.argtypes = [_i32, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_spm_create_from_file.argtypes = [C.c_char_p, C.POINTER(_vp)]
@@ -172,9 +173,9 @@ def lib() -> C.CDLL:
 
 
 def debug_set(key: str, value: Optional[str]) -> None:
-    """Set (or with None: clear) one tuning / test hook of the library (kh_debug_set)."""
-    global _ENV_SEEN
-    _ENV_SEEN = None  # the table no longer mirrors os.environ: the next sync_env() walks it again
+    """Set (or with None: clear) one tuning / test hook of the library (kh_debug_set).  A hook set here stays
+    until it is cleared here: sync_env() only manages the hooks it mirrored from os.environ itself."""
+    _ENV_MIRRORED.pop(key, None)  # from now on the key belongs to the caller, not to the environment mirror
     check(lib().kh_debug_set(key.encode(), None if value is None else str(value).encode()), "kh_debug_set")
 
 
@@ -183,8 +184,8 @@ def debug_get(key: str) -> Optional[str]:
     return None if v is None else v.decode()
 
 
-_HOOK_PREFIXES = ("KH_SHAPE_", "KH_ATTN_", "KH_PG_", "KH_PREFILL")
-_ENV_SEEN = None  # the hook variables as of the last sync_env()
+_HOOK_PREFIXES = ("KH_SHAPE_", "KH_ATTN_", "KH_PG_", "KH_PREFILL", "KH_RING")
+_ENV_MIRRORED = {}  # hook -> value, as last written into the table FROM os.environ by sync_env()
 
 
 def sync_env() -> None:
@@ -192,21 +193,20 @@ def sync_env() -> None:
 
     The library reads the environment once, when it is loaded; afterwards hooks change only through
     kh_debug_set.  The Python binding calls this before every entry point that reads a hook, so
-    `os.environ[...] = ...` / `monkeypatch.setenv` keep working in tests and tools."""
-    global _ENV_SEEN
+    `os.environ[...] = ...` / `monkeypatch.setenv` keep working in tests and tools.  Only keys that came from
+    the environment are managed: a variable that disappears from os.environ is cleared in the table, a hook
+    set through debug_set() is left alone (an environment variable of the same name overrides it)."""
     want = {k: v for k, v in os.environ.items() if k.startswith(_HOOK_PREFIXES)}
-    if want == _ENV_SEEN:  # nothing changed since the last call: no table walk per generate()
+    if want == _ENV_MIRRORED:  # nothing changed since the last call: no table walk per generate()
         return
     L = lib()
-    need = L.kh_debug_list(None, 0)
-    buf = C.create_string_buffer(int(need))
-    L.kh_debug_list(buf, need)
-    have = {k for k in buf.value.decode().split("\n") if k.startswith(_HOOK_PREFIXES)}
-    for k in have - set(want):
+    for k in set(_ENV_MIRRORED) - set(want):
         L.kh_debug_set(k.encode(), None)
+        del _ENV_MIRRORED[k]
     for k, v in want.items():
-        L.kh_debug_set(k.encode(), v.encode())
-    _ENV_SEEN = dict(want)
+        if _ENV_MIRRORED.get(k) != v:
+            L.kh_debug_set(k.encode(), v.encode())
+            _ENV_MIRRORED[k] = v
 
 
 def error_string(code: int) -> str:
@@ -227,6 +227,17 @@ def plan_decode_shapes(dim: int, hidden_dim: int, kv_dim: int, vocab_size: int, 
         raise KhError(rc, "kh_plan_decode_shapes")
     names = ("qkv", "wo", "ffn13", "w2", "cls")
     return {n: dict(zip(("split", "u", "grid", "wg"), out[4 * i:4 * i + 4])) for i, n in enumerate(names)}
+
+
+def plan_decode_ring(dim: int, hidden_dim: int, vocab_size: int, quant: bool, group_size: int = 64) -> dict:
+    """Which int8 decode GEMVs run on the LDS-DMA ring kernels: {ffn13: {slots, grid}, cls: {slots, grid}};
+    slots 0 = the register-tile kernel of plan_decode_shapes (host-only, kh_plan_decode_ring)."""
+    sync_env()
+    out = (_i32 * 4)()
+    rc = lib().kh_plan_decode_ring(dim, hidden_dim, vocab_size, int(quant), group_size, out)
+    if rc != 0:
+        raise KhError(rc, "kh_plan_decode_ring")
+    return {"ffn13": {"slots": out[0], "grid": out[1]}, "cls": {"slots": out[2], "grid": out[3]}}
 
 
 def plan_attention(head_num: int, kv_mul: int, head_size: int, seq_len: int, pos: int) -> dict:

@@ -239,7 +239,16 @@ def synth_image(spec: ModelSpec, seed: int = 1234, device: str | torch.device = 
     """
     device = torch.device(device)
     ents, total = layout(spec)
-    img = torch.empty(total, dtype=torch.uint8, device=device)
+    # Place the image so that the bytes BEHIND the header - what the library uses in place when the image is handed
+    # over on the device - start on a 4-KiB boundary, as they do in the arena kh_model_create_from_file /
+    # _from_host_image allocate.  Every tensor of an exported image is a multiple of 256 bytes long in the BASELINE
+    # geometries, so all weight rows then start on a line boundary; with the int8 header (32 bytes: a 16-byte
+    # aligned, usable address) every row sat 32 bytes off one and each 1-KiB wave request straddled nine 128-byte
+    # lines instead of eight (measured on ffn13 int8: 18.0 vs 17.4 us, profiles/r5_int8_ring_ab.txt).
+    pad = 4096  # hipMalloc's own alignment is at least this
+    buf = torch.empty(total + pad, dtype=torch.uint8, device=device)
+    lead = (-(buf.data_ptr() + spec.header_bytes())) % pad
+    img = buf[lead: lead + total]
     hdr = [spec.dim, spec.hidden_dim, spec.n_layers, spec.n_heads, spec.n_kv_heads,
            spec.vocab_size if spec.shared_classifier else -spec.vocab_size, spec.seq_len]
     if spec.quant:

@@ -83,6 +83,12 @@ struct kh_model {
     int u = 2, split = 1, grid = 1, wg = KH_WG;
   };
   Shape sh_qkv, sh_wo, sh_ffn, sh_w2, sh_cls;
+  // int8 ffn13 / cls on the LDS-DMA ring kernels (kh_fused_ring.h): ring slots per wave (0 = the register-tile
+  // kernel of sh_ffn / sh_cls) and workgroups (256 threads each); chosen by plan_ring
+  struct RingPlan {
+    int ffn_r = 0, ffn_grid = 0, cls_r = 0, cls_grid = 0;
+  };
+  RingPlan ring;
   // graph
   // the decode step captured once as a 1-step graph and once as a KH_GRAPH_STEPS-step graph:
   // consecutive hipGraphLaunch calls leave the GPU idle for ~8 us (measured), so the long
@@ -114,6 +120,8 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
                            int wg_max = KH_WG, bool many_waves = false);
 // launch geometry of the five GEMV kernels of a decode step: qkv, wo, ffn13, w2, cls (host-only)
 void plan_decode_shapes(bool quant, int dim, int hidden_dim, int kv_dim, int vocab_size, kh_model::Shape (&out)[5]);
+// which int8 GEMVs of a decode step run on the LDS-DMA ring kernels, and their launch geometry (host-only)
+void plan_ring(bool quant, int dim, int hidden_dim, int vocab_size, int group_size, kh_model::RingPlan* out);
 int configure_step_kernels(kh_model* m);  // >64 KiB dynamic-LDS opt-in of the hidden-sized GEMVs
 KhAttnArgs fill_attn(kh_model* m, int l);
 void launch_qkv(kh_model* m, int l);

@@ -246,8 +246,12 @@ int finish_create(kh_model* m) {
     plan_decode_shapes(c.is_quant != 0, c.dim, c.hidden_dim, c.kv_dim, c.vocab_size, sh);
     m->sh_qkv = sh[0]; m->sh_wo = sh[1]; m->sh_ffn = sh[2]; m->sh_w2 = sh[3]; m->sh_cls = sh[4];
   }
-  m->nparts = m->sh_cls.grid;
+  plan_ring(c.is_quant != 0, c.dim, c.hidden_dim, c.vocab_size, c.group_size, &m->ring);
+  m->nparts = m->ring.cls_r ? m->ring.cls_grid : m->sh_cls.grid;
   if (dbg("KH_SHAPE_DEBUG")) {
+    if (m->ring.ffn_r || m->ring.cls_r)
+      fprintf(stderr, "[kh] LDS-DMA ring: ffn13 R %d grid %d | cls R %d grid %d (256 threads)\n", m->ring.ffn_r,
+              m->ring.ffn_grid, m->ring.cls_r, m->ring.cls_grid);
     const struct { const char* n; const kh_model::Shape* s; } all[] = {
         {"qkv", &m->sh_qkv}, {"wo", &m->sh_wo}, {"ffn13", &m->sh_ffn}, {"w2", &m->sh_w2}, {"cls", &m->sh_cls}};
     for (const auto& e : all)

@@ -5,6 +5,9 @@
 // meaning as the reference's CUDA kernels, raw device pointers instead of tensor::Tensor.
 // The fused decode path (kh_model_step.hip) reuses the same device cores (kh_gemv.h, kh_attn.h).
 #include "kh_attn.h"
+#include <mutex>
+#include <vector>
+
 #include "kh_common.h"
 #include "kh_gemv.h"
 
@@ -674,12 +677,42 @@ extern "C" int kh_argmax_f32(const float* logits, int64_t n, int32_t* d_out_inde
                      (long long)n, d_out_index);
   return kh_launch_status();
 }
+// The reference's sampler path (ArgmaxSampler::sample -> argmax_kernel_cu, argmax_kernel.cu:53-77) allocates 8 bytes
+// per token and never frees them; rounds 1-4 of this library allocated and freed 4 bytes per call, i.e. a
+// device-wide synchronisation per token.  One 4-byte device word per (device, stream), created on first use and
+// kept for the life of the process (a few bytes per stream ever used; calls on one stream are serialised by the
+// stream itself, calls on different streams use different words).
+namespace {
+struct ArgmaxSlot {
+  int device;
+  void* stream;
+  int32_t* d;
+};
+std::mutex g_argmax_mu;
+std::vector<ArgmaxSlot> g_argmax_slots;
+int argmax_slot(void* stream, int32_t** out) {
+  int dev = 0;
+  KH_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(g_argmax_mu);
+  for (const auto& s : g_argmax_slots)
+    if (s.device == dev && s.stream == stream) {
+      *out = s.d;
+      return KH_OK;
+    }
+  int32_t* d = nullptr;
+  KH_CHECK_HIP(hipMalloc((void**)&d, sizeof(int32_t)));
+  g_argmax_slots.push_back({dev, stream, d});
+  *out = d;
+  return KH_OK;
+}
+}  // namespace
 extern "C" int kh_argmax_f32_host(const float* logits, int64_t n, int64_t* h_out_index,
                                   void* stream) {
   if (!h_out_index) return KH_ERR_INVALID_ARG;
   int32_t* d = nullptr;
-  KH_CHECK_HIP(hipMalloc((void**)&d, sizeof(int32_t)));
-  int rc = kh_argmax_f32(logits, n, d, stream);
+  int rc = argmax_slot(stream, &d);
+  if (rc != KH_OK) return rc;
+  rc = kh_argmax_f32(logits, n, d, stream);
   int32_t h = -1;
   if (rc == KH_OK) {
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int32_t), hipMemcpyDeviceToHost,
@@ -687,7 +720,6 @@ extern "C" int kh_argmax_f32_host(const float* logits, int64_t n, int64_t* h_out
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     rc = e == hipSuccess ? KH_OK : (int)e;
   }
-  (void)hipFree(d);  // unlike the reference (argmax_kernel.cu:76) the 4 B are released
   *h_out_index = h;
   return rc;
 }

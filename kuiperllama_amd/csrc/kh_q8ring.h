@@ -1,0 +1,325 @@
+// kh_q8ring.h — int8 group-dequant GEMV whose weight stream runs through a per-wave LDS ring filled by the
+// DMA path of the vector memory unit (global_load_lds_dwordx4, gfx950).
+//
+// Replaces, for the int8 decode GEMVs, the load-to-VGPR core of kh_gemv.h (reference kernel:
+// kuiper/source/op/kernels/cuda/matmul_kernel.cu:56-87).  Why: with register tiles a wave's bytes in flight
+// are bounded by its VGPRs (8 KiB per wave, 64 KiB per CU on the shipped shapes) and it has nothing in flight
+// while it dequantises; the pure-stream floor of the same bytes is 15-25 % below the shipped kernels
+// (profiles/r3_int8_floors_stream.txt).  Here every wave owns R ring slots in LDS; a slot holds one PIECE PAIR
+// (1 KiB of each of the pair's two rows + the group scale each lane needs).
+// The wave keeps R-1 slots in flight at all times - requested by LDS-DMA, which needs no registers - waits for
+// the oldest with an exact s_waitcnt vmcnt(OPS * (R-1)), reads it with ds_read_b128, re-requests the slot for
+// the piece R positions ahead and only then runs the converts and FMAs.  No wave waits on another wave: the only
+// landing signal LDS-DMA has is the issuing wave's own vmcnt, so the ring is private to the wave and there is no
+// flag, no barrier and no loader/consumer hand-off.
+//
+// Arithmetic: per lane exactly the order of kh_gemv.h::fma_u - lane l owns the 16-byte chunks l, l + 64, ... of
+// the wave's column range in ascending order, 16 sequential FMAs from zero per chunk, one scale FMA per chunk,
+// then the DPP butterfly of wave_sum and the fixed-order combination of SPLIT parts - so results are
+// bit-identical to gemv_pairs (and to the B-token prefill, kh_prefill.h) for the same SPLIT.
+//
+// The compiler does not know that the asm DMA operations occupy vmcnt slots; its own s_waitcnt for a
+// compiler-visible global LOAD would therefore drain the ring.  Hence: no vector load while the ring is live.
+// The activation vector comes through the DMA path too (StagerDma), epilogue operands (residual, sin / cos,
+// bias) through the scalar cache (ld_uniform: lgkmcnt), pointers and sizes are kernel arguments.
+// Stores are fine (nothing waits for them; vmcnt(N) with extra younger stores only over-waits).
+#pragma once
+#include <type_traits>
+
+#include "kh_gemv.h"
+
+#define KH_RING_W 2048                 // two 1-KiB row pieces
+#define KH_RING_SC (KH_RING_W)         // two 256-B scale vectors (one float per lane)
+#define KH_RING_SLOT (KH_RING_W + 512)
+
+__device__ __forceinline__ unsigned kh_lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// 64 lanes x 16 B from (base + voff[lane]) to LDS [dst + 16 * lane]; dst is wave-uniform.  Weights: read once, nt.
+__device__ __forceinline__ void dma_x4(const void* base, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+               :
+               : "v"(voff), "s"(base), "s"(dst)
+               : "memory");
+}
+// the same with the default cache policy (the activation vector: every workgroup reads it, it lives in L2)
+__device__ __forceinline__ void dma_x4_keep(const void* base, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(base), "s"(dst)
+               : "memory");
+}
+// 64 lanes x 4 B to LDS [dst + 4 * lane]
+__device__ __forceinline__ void dma_x1(const void* base, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
+               :
+               : "v"(voff), "s"(base), "s"(dst)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+// A wave-uniform word through the scalar cache (s_load: lgkmcnt, never vmcnt).  For epilogue operands only:
+// read-only tables (sin / cos, bias) and residual words that no OTHER wave writes during the kernel - the one
+// wave that owns row pair p reads x[2p], x[2p+1] before it stores them, so a scalar-cache line that went stale
+// in its neighbours' words still holds the right value in ours; the cache is invalidated at kernel start.
+__device__ __forceinline__ float ld_uniform(const float* p) {
+  return *(const __attribute__((address_space(4))) float*)(unsigned long long)p;
+}
+
+// Input vector staging through the DMA path.  A VGPR-returning load and an LDS-DMA operation do not retire in
+// issue order relative to each other (measured: a vmcnt wait that covered 8 older global_load_dwordx4 behind 28
+// younger DMA operations returned before the loads had landed - every RMSNorm kernel of the first version was
+// wrong while the DMA-only ring data was right), so everything that shares the ring's vmcnt window is a DMA
+// operation: the waves of the workgroup pull the raw vector into the xs area (linear) and the norm weight into
+// its own area with 1-KiB pieces, issued BEFORE the ring prologue, and finish() waits for exactly the prologue's
+// operation count, then permutes (and normalises) in place through registers: the element -> thread mapping and
+// the arithmetic are Stager<NORM, true, MAXV>'s, so the staged vector is bit-identical.
+// Needs M % 256 == 0 (whole 1-KiB pieces); the launcher falls back to the register-tile kernels otherwise.
+// VT: the element -> thread mapping and the norm's reduction tree are those of a VT-thread workgroup (0: the real
+// width); threads past VT only take part in the barriers.  Lets a workgroup of any width (11 waves, ...) stage
+// exactly what the 256-thread kernels stage.
+template <bool NORM, int MAXV, int VT = 0>
+struct StagerDma {
+  const float* x;
+  const float* wnorm;
+  f32x4* xs;         // q8-layout area; receives the raw vector first
+  const f32x4* wraw;  // NORM: raw norm weight area (M floats)
+  int M;
+  __device__ __forceinline__ StagerDma(const float* x_, const float* wnorm_, f32x4* xs_, const void* wraw_, int M_)
+      : x(x_), wnorm(wnorm_), xs(xs_), wraw((const f32x4*)wraw_), M(M_) {}
+  __device__ __forceinline__ void issue() {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = kh_nwaves();
+    const unsigned lane16 = (threadIdx.x & 63u) << 4;
+    const unsigned xs0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kh_lds_addr(xs));
+    const unsigned wr0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kh_lds_addr(wraw));
+    const int npieces = M >> 8;
+    for (int pc = wave; pc < npieces; pc += nw) {
+      dma_x4_keep(x, (unsigned)pc * 1024u + lane16, xs0 + (unsigned)pc * 1024u);
+      if (NORM) dma_x4_keep(wnorm, (unsigned)pc * 1024u + lane16, wr0 + (unsigned)pc * 1024u);
+    }
+  }
+  template <int YOUNGER>
+  __device__ __forceinline__ void finish(float eps, float* red, bool exact) {
+    if (exact)
+      wait_vm<YOUNGER>();
+    else
+      wait_vm<0>();
+    __syncthreads();  // every wave's pieces have landed
+    const int M4 = M >> 2, M16 = M >> 4;
+    const int wgv = VT ? VT : kh_wg();
+    const bool act = (int)threadIdx.x < wgv;
+    f32x4 xv[MAXV], wv[NORM ? MAXV : 1];
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = threadIdx.x + v * wgv;
+      const int ci = (act && i < M4) ? i : 0;
+      xv[v] = xs[ci];
+      if (NORM) wv[v] = wraw[ci];
+    }
+    float rs = 1.f;
+    if (NORM) {
+      float ss = 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const float t = fma4(xv[v], xv[v], 0.f);
+        ss += (act && (int)threadIdx.x + v * wgv < M4) ? t : 0.f;
+      }
+      // block_sum over the wgv / 64 waves that staged; its barriers also separate the raw reads above from the
+      // permuted writes below
+      ss = wave_sum(ss);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvw = wgv >> 6;
+      if (lane == 0 && wave < nvw) red[wave] = ss;
+      __syncthreads();
+      float r = 0.f;
+#pragma unroll
+      for (int w = 0; w < KH_WAVES_MAX; ++w) r += w < nvw ? red[w < nvw ? w : 0] : 0.f;
+      __syncthreads();
+      rs = 1.0f / sqrtf(r / (float)M + eps);
+    } else {
+      __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = threadIdx.x + v * wgv;
+      if (act && i < M4) {
+        f32x4 t = xv[v];
+        if (NORM) {
+          t.x = wv[v].x * (rs * t.x);
+          t.y = wv[v].y * (rs * t.y);
+          t.z = wv[v].z * (rs * t.z);
+          t.w = wv[v].w * (rs * t.w);
+        }
+        xs[q8_slot(i, M16)] = t;
+      }
+    }
+    __syncthreads();
+  }
+};
+
+template <int J, class F>
+__device__ __forceinline__ void ring_tail(int& k, int N, F&& f) {
+  if (N - k == J + 1) {  // uniform
+    f(std::integral_constant<int, J>{});
+    ++k;
+  }
+  if constexpr (J > 0) ring_tail<J - 1>(k, N, f);
+}
+
+// xs (q8 layout) | red[KH_WAVES_MAX] | comb[2 * KH_WAVES_MAX] | pad to 256 | NORM: raw norm weight (M floats) | rings
+__host__ __device__ static inline size_t ring_lds_wraw_off(int M) {
+  const size_t xs_bytes = (size_t)4 * (size_t)(M / 16 + 1) * 16;  // kh_q8_lds_bytes
+  return ((xs_bytes + 3 * KH_WAVES_MAX * sizeof(float)) + 255) & ~(size_t)255;
+}
+__host__ __device__ static inline size_t ring_lds_off(int M, bool norm) {
+  return ring_lds_wraw_off(M) + (norm ? (size_t)M * 4 : 0);
+}
+static inline size_t ring_lds_bytes(int M, bool norm, int waves, int R) {
+  return ring_lds_off(M, norm) + (size_t)waves * R * KH_RING_SLOT;
+}
+
+// The row-pair loop.  Same work decomposition as gemv_pairs: work item = (pair p, column part), p = gp + it * np.
+//   PAIR(p)        -> RowsQ8 of work item p (scalar address arithmetic)
+//   AUX(p)         -> small struct of epilogue operands fetched through the scalar cache (ld_uniform) when the
+//                     item's first piece is consumed - no vector load may be issued while the ring is live
+//   ISSUE()        -> StagerDma::issue
+//   FINISH(exact)  -> StagerDma::finish<R * 4>(..., exact)
+//   EPI(p, s0, s1, aux) -> epilogue with the two dot products
+// BLOCKED: workgroup b owns the contiguous items [b * ipw, (b + 1) * ipw), ipw = ceil(total / grid), and its waves
+// take them round-robin - with one workgroup per CU every CU streams the same number of bytes whatever the wave
+// count (gemv_pairs' mapping p = gp + it * np gives the first workgroups one item more per wave than the last).
+template <int SPLIT, int R, bool BLOCKED, class PairFn, class AuxFn, class IssueFn, class FinishFn, class EpiFn>
+__device__ __forceinline__ void ring_pairs(int M, int gshift, const f32x4* xs, int total, int lane, float* comb,
+                                           char* ring_base, PairFn&& PAIR, AuxFn&& AUX, IssueFn&& ISSUE,
+                                           FinishFn&& FINISH, EpiFn&& EPI) {
+  constexpr int OPS = 4;
+  static_assert(SPLIT == 1 || SPLIT == 2 || SPLIT == 4, "SPLIT must be 1, 2 or 4");
+  static_assert(R >= 1 && R * OPS <= 60, "ring depth exceeds the vmcnt range");
+  const int Mc = M >> 4, plane = Mc + 1;
+  const int vb = (int)blockIdx.x, vgrid = (int)gridDim.x;
+  const int PPW = kh_nwaves() / SPLIT;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int part = wave & (SPLIT - 1);
+  const int ipw = BLOCKED ? (total + vgrid - 1) / vgrid : 0;
+  const int gp = BLOCKED ? vb * ipw + wave / SPLIT : vb * PPW + wave / SPLIT;
+  const int np = BLOCKED ? PPW : vgrid * PPW;
+  if constexpr (BLOCKED) total = (vb + 1) * ipw < total ? (vb + 1) * ipw : total;  // this workgroup's end
+  const int Q = (((Mc + SPLIT - 1) / SPLIT) + 3) & ~3;  // gemv_pairs' column quantum
+  const int cb = part * Q;
+  const int ce = cb + Q < Mc ? cb + Q : Mc;
+  char* const ring = ring_base + (size_t)wave * (R * KH_RING_SLOT);
+  const unsigned ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kh_lds_addr(ring));
+
+  ISSUE();  // the vector's pieces leave before any of the work-item arithmetic below (an integer division among it)
+  __builtin_amdgcn_sched_barrier(0);
+  const int ppi = (ce - cb + KH_WAVE - 1) >> 6;  // pieces per work item
+  const int my_items = gp < total ? (total - gp + np - 1) / np : 0;
+  const int N = my_items * ppi;
+
+  // ---- the issue side: runs R pieces ahead of the consume side
+  int pi = gp, ci = cb;
+  unsigned si = 0;
+  RowsQ8 rw = PAIR(gp < total ? gp : 0);
+  auto issue1 = [&]() __attribute__((always_inline)) {
+    const int idx = ci + lane;
+    const int cidx = idx < ce ? idx : 0;  // clamped like load_u; masked at the FMA
+    const unsigned d = ring0 + si;
+    dma_x4(rw.w0, (unsigned)cidx << 4, d);
+    dma_x4(rw.w1, (unsigned)cidx << 4, d + 1024);
+    const unsigned go = (unsigned)((cidx << 4) >> gshift) << 2;
+    dma_x1(rw.sc0, go, d + KH_RING_SC);
+    dma_x1(rw.sc1, go, d + KH_RING_SC + 256);
+    ci += KH_WAVE;
+    if (ci >= ce) {
+      ci = cb;
+      pi += np;
+      if (pi < total) rw = PAIR(pi);
+    }
+    si += KH_RING_SLOT;
+    if (si == (unsigned)(R * KH_RING_SLOT)) si = 0;
+  };
+  const int n0 = N < R ? N : R;
+  for (int k = 0; k < n0; ++k) issue1();
+  FINISH(n0 == R);
+
+  // ---- the consume side
+  int pc = gp, cc = cb;
+  unsigned sc = 0;
+  float a0 = 0.f, a1 = 0.f;
+  auto aux = AUX(gp < total ? gp : 0);
+  auto finish_item = [&]() __attribute__((always_inline)) {
+    float s0 = wave_sum(a0), s1 = wave_sum(a1);
+    if constexpr (SPLIT == 1) {
+      EPI(pc, s0, s1, aux);
+    } else {
+      if (lane == 0) {
+        comb[2 * wave] = s0;
+        comb[2 * wave + 1] = s1;
+      }
+      __syncthreads();
+      if (part == 0) {
+        s0 = comb[2 * wave];
+        s1 = comb[2 * wave + 1];
+#pragma unroll
+        for (int k = 1; k < SPLIT; ++k) {
+          s0 += comb[2 * (wave + k)];
+          s1 += comb[2 * (wave + k) + 1];
+        }
+        EPI(pc, s0, s1, aux);
+      }
+      __syncthreads();
+    }
+  };
+  auto consume = [&](auto wtag, auto refill) __attribute__((always_inline)) {
+    wait_vm<decltype(wtag)::value>();
+    const char* s = ring + sc;
+    const i32x4 q0 = ((const i32x4*)s)[lane];
+    const i32x4 q1 = ((const i32x4*)(s + 1024))[lane];
+    const float g0 = ((const float*)(s + KH_RING_SC))[lane];
+    const float g1 = ((const float*)(s + KH_RING_SC + 256))[lane];
+    const int idx = cc + lane;
+    const bool in = idx < ce;
+    const int cx = in ? idx : 0;
+    const f32x4 x0 = xs[cx], x1 = xs[plane + cx], x2 = xs[2 * plane + cx], x3 = xs[3 * plane + cx];
+    // the slot's bytes are in registers before the slot is handed back to the DMA engine
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (decltype(refill)::value) issue1();
+    if (cc == cb) aux = AUX(pc);  // uniform; scalar loads, consumed at the end of the item
+    float t0 = 0.f, t1 = 0.f;
+    t0 = dot4_i8(q0.x, x0, t0);
+    t0 = dot4_i8(q0.y, x1, t0);
+    t0 = dot4_i8(q0.z, x2, t0);
+    t0 = dot4_i8(q0.w, x3, t0);
+    t1 = dot4_i8(q1.x, x0, t1);
+    t1 = dot4_i8(q1.y, x1, t1);
+    t1 = dot4_i8(q1.z, x2, t1);
+    t1 = dot4_i8(q1.w, x3, t1);
+    a0 = __builtin_fmaf(in ? g0 : 0.f, t0, a0);
+    a1 = __builtin_fmaf(in ? g1 : 0.f, t1, a1);
+    cc += KH_WAVE;
+    sc += KH_RING_SLOT;
+    if (sc == (unsigned)(R * KH_RING_SLOT)) sc = 0;
+    if (cc >= ce) {
+      finish_item();
+      pc += np;
+      cc = cb;
+      a0 = a1 = 0.f;
+    }
+  };
+  int k = 0;
+  for (; k + R < N; ++k) consume(std::integral_constant<int, OPS*(R - 1)>{}, std::true_type{});
+  // the tail: everything is requested, j + 1 pieces are left -> j pieces are younger than the one waited for
+  ring_tail<R - 1>(k, N, [&](auto jt) __attribute__((always_inline)) {
+    consume(std::integral_constant<int, OPS * decltype(jt)::value>{}, std::false_type{});
+  });
+  if constexpr (SPLIT > 1) {
+    const int span = BLOCKED ? total - vb * ipw : total;  // items the workgroup's waves share
+    const int iters = span > 0 ? (span + np - 1) / np : 0;
+    for (int e = my_items; e < iters; ++e) {
+      __syncthreads();
+      __syncthreads();
+    }
+  }
+}

@@ -17,9 +17,19 @@
 // to HIP) and the getters treat kDeviceCUDA as the HIP branch (-DKH_REF_CUDA_TAG_IS_HIP).  test_ref_binding /
 // test_ref_layers are the builds where every tensor comes from include/kuiper_hip_alloc.hpp instead.
 //
-// usage: test_ref_model <model.bin> <tokenizer.model> <steps> <prompt ids, comma separated> [expected words, comma separated]
+// The same TU builds the Qwen twin: -DKH_REF_MODEL_QWEN2 selects model::Qwen2Model (kuiper/source/model/qwen2.cpp:
+// bias wiring :147-167, 307-332) - a second binary, oracle/_ref/test_ref_model_qwen2, because the reference's llama3.h
+// and qwen2.h share one include guard.  It is compiled WITHOUT -DQWEN2_SUPPORT (that switch only selects the tiktoken
+// tokenizer, the rotate-half RoPE and eps 1e-6 in the reference's own kernels); the RoPE flavour / theta / eps the
+// model runs with are runtime state here (kuiper_hip::flavor(), bound to the model's stream at init).
+//
+// usage: test_ref_model <model.bin> <tokenizer.model> <steps> <prompt ids, comma separated> <expected words | ->
+//                       [--quant] [--flavor rope_mode,rms_eps,rope_theta]
 // Runs the loop of demo/main.cpp:5-47 (prompt phase: predict with is_prompt, then greedy) and prints the words, the
 // tokens/s of the reference's per-op host loop, and OK when the words equal the expected ones.
+//   --quant   is_quant_model = true: the int8 reader of llama3.cpp:184-288 (create_param_quant_layers) and
+//             MatmulLayer's int8 forward through get_matmul_kernel_quant8
+//   --flavor  the reference's compile-time switches as runtime values (e.g. 1,1e-5,500000 = LLAMA3_SUPPORT)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -28,9 +38,19 @@
 #include <string>
 #include <vector>
 
+#include <cstring>
+
 #include "kernels_interface.h"
 #include "kuiper_hip_adapter.hpp"
+#ifdef KH_REF_MODEL_QWEN2
+#include "model/qwen2.h"
+using RefModel = model::Qwen2Model;
+static const char* const kRefModelName = "Qwen2Model";
+#else
 #include "model/llama3.h"
+using RefModel = model::LLama2Model;
+static const char* const kRefModelName = "LLama2Model";
+#endif
 
 using HipK = kuiper_hip::Kernels<tensor::Tensor, kernel::CudaConfig, base::DeviceType>;
 
@@ -62,7 +82,7 @@ static std::vector<int32_t> parse_ids(const char* s) {
 }
 
 // demo/main.cpp:5-47 with the prompt given as token ids
-static std::vector<int32_t> generate(const model::LLama2Model& model, std::vector<int32_t> tokens, int total_steps) {
+static std::vector<int32_t> generate(const RefModel& model, std::vector<int32_t> tokens, int total_steps) {
   const int32_t prompt_len = (int32_t)tokens.size();
   int32_t pos = 0, next = -1;
   bool is_prompt = true;
@@ -105,9 +125,33 @@ int main(int argc, char** argv) {
   }
   const int steps = std::atoi(argv[3]);
   const std::vector<int32_t> prompt = parse_ids(argv[4]);
-  const std::vector<int32_t> want = argc > 5 ? parse_ids(argv[5]) : std::vector<int32_t>();
-  model::LLama2Model model(base::TokenizerType::kEncodeSpe, argv[2], argv[1], /*is_quant_model=*/false);
+  const std::vector<int32_t> want =
+      (argc > 5 && std::strcmp(argv[5], "-") != 0) ? parse_ids(argv[5]) : std::vector<int32_t>();
+  bool quant = false;
+  for (int i = 6; i < argc; ++i) {
+    if (!std::strcmp(argv[i], "--quant")) {
+      quant = true;
+    } else if (!std::strcmp(argv[i], "--flavor") && i + 1 < argc) {
+      int mode = 0;
+      float eps = 1e-5f, theta = 10000.f;
+      if (std::sscanf(argv[++i], "%d,%f,%f", &mode, &eps, &theta) != 3) {
+        std::printf("bad --flavor (rope_mode,rms_eps,rope_theta)\n");
+        return 2;
+      }
+      kuiper_hip::flavor() = kuiper_hip::Flavor{mode, eps, theta};
+    } else {
+      std::printf("unknown argument %s\n", argv[i]);
+      return 2;
+    }
+  }
+  const kuiper_hip::Flavor mine = kuiper_hip::flavor();
+  RefModel model(base::TokenizerType::kEncodeSpe, argv[2], argv[1], /*is_quant_model=*/quant);
   const base::Status st = model.init(base::DeviceType::kDeviceCUDA);
+  // init() computed the sin / cos table on the model's stream, which bound that stream to `mine`
+  // (kuiper_hip_adapter.hpp: bind_flavor): from here on the process default belongs to the next model.  Set it
+  // to something this model must NOT pick up - a second model with another flavour in the same process.
+  kuiper_hip::flavor() = kuiper_hip::Flavor{mine.rope_mode == KH_ROPE_HALF ? KH_ROPE_INTERLEAVED : KH_ROPE_HALF,
+                                            mine.rms_eps * 100.f, mine.rope_theta * 3.f};
   if (!st) {
     std::printf("FAIL init: %s\n", st.get_err_msg().c_str());
     return 1;
@@ -126,9 +170,10 @@ int main(int argc, char** argv) {
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("words:");
   for (int32_t w : words) std::printf(" %d", w);
-  std::printf("\nreference LLama2Model on the HIP kernels: %d steps in %.2f ms = %.1f tokens/s (host loop of "
-              "llama3.cpp:147-167, one launch per operator, pos on the host)\n",
-              steps, sec * 1e3, steps / sec);
+  std::printf("\nreference %s%s on the HIP kernels (rope mode %d, eps %g, theta %g): %d steps in %.2f ms = %.1f tokens/s "
+              "(host loop of llama3.cpp:147-167, one launch per operator, pos on the host)\n",
+              kRefModelName, quant ? " [int8]" : "", (int)mine.rope_mode, (double)mine.rms_eps, (double)mine.rope_theta, steps,
+              sec * 1e3, steps / sec);
   if (!want.empty()) {
     if (words != want) {
       size_t i = 0;

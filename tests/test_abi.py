@@ -82,16 +82,29 @@ def test_debug_hooks_live_in_one_table_not_in_getenv(lib, monkeypatch):
     assert "KH_TEST_HOOK" in buf.value.decode().split("\n")
     _ffi.debug_set("KH_TEST_HOOK", None)
     assert _ffi.debug_get("KH_TEST_HOOK") is None
-    # a shape hook set through the API changes the plan; sync_env() mirrors os.environ (here: clears it)
+    # a shape hook set through the API changes the plan and SURVIVES the binding's environment mirror
+    # (sync_env only manages the keys it took from os.environ); an environment variable of the same name
+    # overrides it while it exists; clearing goes through the API again
     base = _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"]
     _ffi.debug_set("KH_SHAPE_FFN", "1,4,256,256")
     out = (C.c_int32 * 20)()
     assert lib.kh_plan_decode_shapes(2048, 8192, 512, 128256, 0, out) == 0
     assert list(out[8:12]) == [1, 4, 256, 256]
-    assert _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"] == base  # env has no such hook
+    assert _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"]["grid"] == 256  # sync_env left it alone
     monkeypatch.setenv("KH_SHAPE_FFN", "1,4,512,256")
     assert _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"]["grid"] == 512
     monkeypatch.delenv("KH_SHAPE_FFN")
+    assert _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"] == base  # the mirrored key is cleared
+    _ffi.debug_set("KH_SHAPE_FFN", None)
+    # the LDS-DMA ring plan: int8 geometries with whole 1-KiB pieces of the input vector take it, KH_RING=0 turns it off
+    assert _ffi.plan_decode_ring(4096, 11008, 32000, True) == {"ffn13": {"slots": 2, "grid": 512}, "cls": {"slots": 2, "grid": 512}}
+    assert _ffi.plan_decode_ring(512, 1408, 501, True) == {"ffn13": {"slots": 2, "grid": 352}, "cls": {"slots": 2, "grid": 63}}
+    assert _ffi.plan_decode_ring(2048, 8192, 128256, False)["ffn13"]["slots"] == 0   # fp32
+    assert _ffi.plan_decode_ring(448, 1216, 3000, True)["cls"]["slots"] == 0        # 448 floats: no whole pieces
+    assert _ffi.plan_decode_ring(8192, 28672, 128256, True)["ffn13"]["slots"] == 0  # 32 floats per staging thread
+    monkeypatch.setenv("KH_RING", "0")
+    assert _ffi.plan_decode_ring(4096, 11008, 32000, True)["ffn13"]["slots"] == 0
+    monkeypatch.delenv("KH_RING")
     _ffi.sync_env()
     csrc = os.path.join(ROOT, "kuiperllama_amd", "csrc")
     for f in os.listdir(csrc):

@@ -273,6 +273,48 @@ def test_deferred_split_merge_equals_in_launch_merge(gpu, oracle, name):
     mi.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,hidden,vocab,heads", [(512, 1408, 501, 8), (256, 704, 1000, 4), (1024, 2816, 32000, 8)])
+def test_int8_ring_kernels_equal_register_tile_kernels(gpu, oracle, monkeypatch, dim, hidden, vocab, heads):
+    """The int8 ffn13 / classifier launches on the LDS-DMA ring kernels (kh_fused_ring.h: weights HBM -> LDS ring
+    by DMA -> ds_read, input vector staged through the DMA path, default for geometries plan_decode_ring accepts)
+    against the register-tile kernels (KH_RING=0): the per-lane arithmetic is the same, so logits must be
+    IDENTICAL at every position, eager and under graph replay - incl. an odd vocabulary (the classifier's last
+    row pair is one row), partial 1-KiB pieces (dim 256: 16 of 64 lanes) and several items per wave - and both sit
+    within the int8 tolerance of the oracle."""
+    from kuiperllama_amd import _ffi
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.ModelSpec(dim, hidden, 2, heads, heads, vocab, 64, False, binfmt.FAMILY_LLAMA, True, 64,
+                            binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, f"ring-{dim}")
+    plan = _ffi.plan_decode_ring(dim, hidden, vocab, True)
+    assert plan["ffn13"]["slots"] == 2 and plan["cls"]["slots"] == 2
+    img_d, img_h = _synth(spec, 91, gpu)
+    m_ring = KuiperModel.from_device_image(img_d, spec)
+    monkeypatch.setenv("KH_RING", "0")
+    assert _ffi.plan_decode_ring(dim, hidden, vocab, True)["ffn13"]["slots"] == 0
+    m_reg = KuiperModel.from_device_image(img_d, spec)
+    monkeypatch.delenv("KH_RING")
+    om = oracle.OracleModel.from_spec(img_h, spec)
+    rng = np.random.default_rng(5)
+    toks = [int(t) for t in rng.integers(0, vocab, 12)]
+    for pos, tok in enumerate(toks):
+        a = m_ring.predict(tok, pos, exec="fused")
+        la = m_ring.logits()
+        b = m_reg.predict(tok, pos, exec="fused")
+        lb = m_reg.logits()
+        assert np.array_equal(la, lb), f"pos {pos}: ring vs register tiles differ by {np.abs(la - lb).max():.3e}"
+        assert a == b
+        lo = om.forward(tok, pos)
+        assert np.abs(la - lo).max() <= FULL_LOGIT_ATOL_Q8, f"pos {pos}: |logit - oracle| {np.abs(la - lo).max():.3e}"
+    ga, _ = m_ring.generate([1, 7], 40, exec="graph")
+    gb, _ = m_reg.generate([1, 7], 40, exec="graph")
+    gc, _ = m_ring.generate([1, 7], 40, exec="fused")
+    assert ga == gb == gc
+    assert np.array_equal(m_ring.logits(), m_reg.logits())
+    m_ring.close()
+    m_reg.close()
+
+
 def test_loader_entry_points_agree(gpu):
     from kuiperllama_amd.model import KuiperModel
     spec, img, toks, ref = load_golden("ref_llama_mha_untied")
