@@ -62,9 +62,11 @@ inline Flavor& flavor() {
 // Per-stream flavours, so that a Llama and a Qwen model can live in one process (the reference cannot: one
 // build, one #ifdef).  Every model object of the reference owns a stream (llama3.cpp:117-125) and passes it to
 // every kernel; RMSNorm / RoPE / the sin-cos table look the flavour up by that stream and fall back to the
-// process default.  sin_cos_cache_calc - the first kernel Model::init issues on its stream - BINDS the stream to
-// the default current at that moment: set flavor(), call model.init(), and the model keeps that flavour
-// whatever flavor() is changed to for the next model.  bind_flavor / unbind_flavor do the same explicitly.
+// process default.  Nothing binds by itself.  The model's stream is private to the reference's model classes, but the
+// one-line forward a port writes for kernel::sin_cos_cache_calc_cu - the first kernel
+// Model::init issues, on that very stream - sees it: `bind_flavor(stream, flavor())` there pins the default of
+// that moment to the model (tests/cpp/test_ref_model.cpp does exactly this): set flavor(), call model.init(), and
+// the model keeps that flavour whatever flavor() is changed to for the next model.
 namespace detail {
 struct BoundFlavor {
   void* stream;
@@ -208,13 +210,11 @@ struct Kernels {
           "kh_rope_f32");
   }
   // sin_cos_cache_calc_cu (cuda/rope_kernel.cuh:9-10); Stream = cudaStream_t in the reference.
-  // theta is an #ifdef there (cuda/rope_kernel.cu:124-151), the flavour's rope_theta here.  Model::init calls
-  // this once, on the model's own stream, before any other kernel: the stream is bound to the process default
-  // of this moment (see bind_flavor), which is what makes a second model with another flavour possible.
+  // theta is an #ifdef there (cuda/rope_kernel.cu:124-151), the flavour's rope_theta here (the stream's bound
+  // flavour, else the process default - see bind_flavor).
   template <class Stream>
   static void sin_cos_cache_calc(int head_size, int max_seq_len, const Tensor& sin_cache,
                                  const Tensor& cos_cache, Stream stream) {
-    bind_flavor((void*)stream, flavor());
     check(kh_sincos_cache_f32(head_size, max_seq_len, flavor_of((void*)stream).rope_theta, mut<float>(sin_cache),
                               mut<float>(cos_cache), (void*)stream),
           "kh_sincos_cache_f32");

@@ -143,16 +143,18 @@ def build_ref_layers() -> str | None:
 REF_MODEL_BIN = os.path.normpath(os.path.join(_PKG, "..", "oracle", "_ref", "test_ref_model"))
 
 
-def build_ref_model() -> str | None:
+def build_ref_model(qwen2: bool = False) -> str | None:
     """tests/cpp/test_ref_model.cpp: the reference's OWN model::LLama2Model (model/{model,llama3,raw_model_data}.cpp,
     sampler/argmax_sampler.cpp, op/encode.cpp compiled where they lie) over the HIP getters + libkuiper_hip.so
-    (oracle/Makefile `ref_model`).  Only where the reference checkout exists; the binary travels to the GPU box."""
+    (oracle/Makefile `ref_model`); qwen2=True: the model::Qwen2Model twin (model/qwen2.cpp, `ref_model_qwen2`).
+    Only where the reference checkout exists; the binary travels to the GPU box."""
+    exe = REF_MODEL_BIN + ("_qwen2" if qwen2 else "")
     if not os.path.isdir(os.path.join(REF_ROOT, "kuiper", "include")):
-        return REF_MODEL_BIN if os.path.exists(REF_MODEL_BIN) else None
+        return exe if os.path.exists(exe) else None
     build_lib()
     subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
-                           "ref_model", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
-    return REF_MODEL_BIN
+                           "ref_model_qwen2" if qwen2 else "ref_model", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
+    return exe
 
 
 def kernel_sources_sha1() -> str:

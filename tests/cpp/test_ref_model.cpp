@@ -58,6 +58,9 @@ namespace kernel {
 // cuda/rope_kernel.cuh:9-10 and cuda/argmax_kernel.cuh:4: the two direct calls of the model level
 void sin_cos_cache_calc_cu(int head_size, int max_seq_len, const tensor::Tensor& sin_cache, const tensor::Tensor& cos_cache,
                            cudaStream_t stream) {
+  // Model::init's first kernel, on the model's own (private) stream: pin the flavour current NOW to that stream, so
+  // the model keeps it when the process default moves on to the next model (kuiper_hip_adapter.hpp: bind_flavor)
+  kuiper_hip::bind_flavor((void*)stream, kuiper_hip::flavor());
   HipK::sin_cos_cache_calc<cudaStream_t>(head_size, max_seq_len, sin_cache, cos_cache, stream);
 }
 size_t argmax_kernel_cu(const float* input_ptr, size_t size, void* stream) { return HipK::argmax(input_ptr, size, stream); }
@@ -147,8 +150,8 @@ int main(int argc, char** argv) {
   const kuiper_hip::Flavor mine = kuiper_hip::flavor();
   RefModel model(base::TokenizerType::kEncodeSpe, argv[2], argv[1], /*is_quant_model=*/quant);
   const base::Status st = model.init(base::DeviceType::kDeviceCUDA);
-  // init() computed the sin / cos table on the model's stream, which bound that stream to `mine`
-  // (kuiper_hip_adapter.hpp: bind_flavor): from here on the process default belongs to the next model.  Set it
+  // init() computed the sin / cos table on the model's stream and the forward above bound that stream to `mine`:
+  // from here on the process default belongs to the next model.  Set it
   // to something this model must NOT pick up - a second model with another flavour in the same process.
   kuiper_hip::flavor() = kuiper_hip::Flavor{mine.rope_mode == KH_ROPE_HALF ? KH_ROPE_INTERLEAVED : KH_ROPE_HALF,
                                             mine.rms_eps * 100.f, mine.rope_theta * 3.f};

@@ -143,23 +143,43 @@ def test_demo_cli_text_prompt_with_sentencepiece_tokenizer(gpu, oracle, tmp_path
     assert tok.decode(want) == spm.SentencePieceProcessor(model_file=tok_path).decode(want)
 
 
+# name -> (reference class, extra arguments of oracle/_ref/test_ref_model[_qwen2]); the golden's own spec gives the flavour
+_REF_MODEL_CASES = {
+    "ref_llama_gqa_tied": ("llama", []),
+    "ref_llama_mha_untied": ("llama", []),
+    "mid-size-tinyllama-geometry": ("llama", []),
+    # the int8 reader + forward: llama3.cpp:184-288 (create_param_quant_layers), MatmulLayer's int8 branch
+    "ref_llama_int8_untied": ("llama", ["--quant"]),
+    # model::Qwen2Model: the q / k / v bias wiring of qwen2.cpp:147-167, 307-332 (the reference exporter's own bytes)
+    "ref_qwen_bias_interleaved": ("qwen2", []),
+    # a non-default flavour at run time: the LLAMA3_SUPPORT / QWEN2_SUPPORT builds of the reference (rotate-half RoPE,
+    # theta 5e5 / 1e6, eps 1e-5 / 1e-6) on HF-exported weights
+    "hf_llama_half": ("llama", ["--flavor", "1,1e-5,500000"]),
+    "hf_qwen2_half": ("qwen2", ["--flavor", "1,1e-6,1000000"]),
+}
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ref_llama_gqa_tied", "ref_llama_mha_untied", "mid-size-tinyllama-geometry"])
+@pytest.mark.parametrize("name", sorted(_REF_MODEL_CASES))
 def test_reference_model_object_decodes_on_gpu(gpu, oracle, tmp_path, name):
-    """The reference's OWN model::LLama2Model - model.cpp / llama3.cpp / raw_model_data.cpp / argmax_sampler.cpp /
-    encode.cpp compiled where they lie, over its own op::*Layer classes - loads a .bin from a FILE, init(kDeviceCUDA)
-    + the demo/main.cpp loop, every operator landing in libkuiper_hip.so through the getters of INTEGRATION.md
-    (oracle/_ref/test_ref_model): the words it produces are the oracle's, on the two reference-exporter goldens and
-    on a 4-layer TinyLlama-geometry model, where the tokens/s of the reference's per-operator host loop is printed
-    next to the fused hipGraph path of this library on the same image."""
+    """The reference's OWN model objects - model::LLama2Model (fp32 and is_quant_model = true) and model::Qwen2Model,
+    i.e. model.cpp / llama3.cpp / qwen2.cpp / raw_model_data.cpp / argmax_sampler.cpp / encode.cpp compiled where they
+    lie, over its own op::*Layer classes - load a .bin from a FILE, init(kDeviceCUDA) + the demo/main.cpp loop, every
+    operator landing in libkuiper_hip.so through the getters of INTEGRATION.md (oracle/_ref/test_ref_model[_qwen2]):
+    the words they produce are the oracle's - on the reference exporter's fp32 / int8 / Qwen-bias goldens, on
+    HF-exported goldens run with the rotate-half flavours set at RUN time (bound to the model's stream at init; the
+    binary then flips the process default to prove the model does not follow it), and on a 4-layer TinyLlama-geometry
+    model, where the tokens/s of the reference's per-operator host loop is printed next to the fused hipGraph path
+    of this library on the same image."""
     import torch
     from conftest import GOLDEN, load_golden
     from kuiperllama_amd import binfmt
     from kuiperllama_amd.model import KuiperModel
-    exe = build.build_ref_model()
+    klass, extra = _REF_MODEL_CASES[name]
+    exe = build.build_ref_model(qwen2=(klass == "qwen2"))
     if exe is None or not os.path.exists(exe):
         pytest.skip("oracle/_ref/test_ref_model not built (no reference checkout at build time)")
-    if name.startswith("ref_"):
+    if name.startswith(("ref_", "hf_")):
         spec, img, _, _ = load_golden(name)
         steps, prompt = min(24, spec.seq_len), [1, 7, 3]
     else:
@@ -171,12 +191,14 @@ def test_reference_model_object_decodes_on_gpu(gpu, oracle, tmp_path, name):
     img.tofile(path)
     want = oracle.OracleModel.from_spec(img, spec).generate(prompt, steps)
     r = subprocess.run([exe, str(path), os.path.join(GOLDEN, "spm_llama_like.model"), str(steps),
-                        ",".join(map(str, prompt)), ",".join(map(str, want))],
+                        ",".join(map(str, prompt)), ",".join(map(str, want))] + extra,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"OK {steps} words equal the expected ones" in r.stdout
+    assert ("Qwen2Model" if klass == "qwen2" else "LLama2Model") in r.stdout
+    assert ("[int8]" in r.stdout) == ("--quant" in extra)
     ref_tok_s = float(r.stdout.split(" = ")[1].split(" tokens/s")[0])
-    if not name.startswith("ref_"):
+    if not name.startswith(("ref_", "hf_")):
         m = KuiperModel.from_host_image(img, spec)
         m.generate(prompt, steps, exec="graph")
         words, ms = m.generate(prompt, steps, exec="graph")
