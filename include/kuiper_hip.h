@@ -167,6 +167,22 @@ typedef struct kh_model_opts {
 /* decode attention at positions that need several time splits: merge the split partials inside the
  * attention launch (ticket + last arriver) instead of in the wo kernel that follows (the default) */
 #define KH_FLAG_ATTN_MERGE_IN_LAUNCH 1
+/* the in-launch merge of time splits (operator entry points, prompt slices, the GQA group path, and everything
+ * under KH_FLAG_ATTN_MERGE_IN_LAUNCH) orders its hand-over with agent-scope release / acquire FENCES instead of the
+ * default write-through stores + drained vmcnt + sc1 loads (csrc/kh_attn.h: attn_publish_barrier).  Same
+ * results; 1-2 us slower per layer at positions that need several splits.  Hook KH_ATTN_FENCED=1 does the same
+ * for models created while it is set and for kh_mha_decode_f32 / kh_mha_f32. */
+#define KH_FLAG_ATTN_MERGE_FENCED 2
+/* The prompt phase of kh_model_generate*.  The reference feeds the prompt one token per forward pass
+ * (demo/main.cpp:20-22), so its prompt phase is, bit for bit, its decode path.  Two batched prompt paths exist here:
+ *  - default: prompts with >= 16 fed-only tokens run as fp32-MFMA GEMMs (kh_model_prefill_gemm, 45-60 k prompt
+ *    tokens/s on Llama-3.2-1B): K/V rows equal to fp32 round-off, i.e. the greedy continuation can differ from the
+ *    reference's at near-ties (kh_model_first_sample reports the margin of the first sampled step);
+ *  - KH_FLAG_PREFILL_EXACT: every prompt runs on the B-token VALU kernels (kh_model_prefill, 5.9 k prompt
+ *    tokens/s): K/V rows and every later logit are bit-identical to the token-by-token prompt phase - what a
+ *    drop-in user who needs token identity with the reference's own prompt phase sets.
+ * kh_first_sample.prefill_mode says which one the last generate took.  The test hook KH_PREFILL overrides both. */
+#define KH_FLAG_PREFILL_EXACT 4
 
 typedef struct kh_config {
   int32_t dim, hidden_dim, layer_num, head_num, kv_head_num, vocab_size, seq_len;
@@ -251,9 +267,10 @@ int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t po
  * remainder; env KH_PG_CHUNK = 16..512 sets another pass size) (v_mfma_f32_16x16x4_f32, exact fp32 arithmetic, tokens on
  * the MFMA N dimension; int8 weights dequantised per element in registers).  The K/V rows agree
  * with the token-by-token path to fp32 round-off (different summation order), not bit for bit.
- * kh_model_generate* use it for prompts with >= 16 fed-only tokens - so for such prompts the greedy
- * tokens carry this tolerance too and can differ from the token-by-token prompt phase at near-ties;
- * env KH_PREFILL = 0 | token | gemv | gemm overrides (gemv = the bit-identical path; any other
+ * kh_model_generate* use it for prompts with >= 16 fed-only tokens unless the model was created with
+ * KH_FLAG_PREFILL_EXACT - so for such prompts the greedy tokens carry this tolerance too and can differ from the
+ * token-by-token prompt phase at near-ties;
+ * hook KH_PREFILL = 0 | token | gemv | gemm overrides (gemv = the bit-identical path; any other
  * value makes generate return KH_ERR_INVALID_ARG).  KH_ERR_UNSUPPORTED: head_size <= 32, dim/hidden not a multiple of 16 (fp32) /
  * 64 (int8), int8 group size != 64. */
 int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32_t n, int32_t pos0);
@@ -297,7 +314,7 @@ int kh_plan_attention(int32_t head_num, int32_t kv_mul, int32_t head_size, int32
 int kh_plan_prefill_shape(int32_t epi, int32_t T, int32_t rows, int32_t K, int32_t is_quant,
                           int32_t r2_ok, int32_t* out7);
 
-/* Tuning / test hooks.  Every hook the library honours (KH_SHAPE_<QKV|WO|FFN|W2|CLS>, KH_RING, KH_ATTN_WG,
+/* Tuning / test hooks.  Every hook the library honours (KH_SHAPE_<QKV|WO|FFN|W2|CLS>, KH_RING, KH_ATTN_WG, KH_ATTN_FENCED,
  * KH_ATTN_TLONG, KH_ATTN_DEFER (0 = never merge time splits in the wo kernel), KH_ATTN_DEFER_MAX (active splits up to
  * which it does), KH_PREFILL, KH_PG_<CHUNK|SHAPE_*|SOLO|KZ|ATTN|ATTN_QT|ROPE_FUSE|DEBUG>,
  * KH_SHAPE_DEBUG) lives in ONE process-wide key -> value table, seeded once from the KH_* variables of

@@ -68,8 +68,32 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_variant(name: str, defines: list[str]) -> str:
+    """Experiment build: kuiperllama_amd/lib/<name>.so = the library with extra -D flags (KH_LIB selects it at run
+    time, kuiperllama_amd/_ffi.py).  Used by tools/gpu_job_*.sh for same-box A/Bs of compile-time constants."""
+    out = os.path.join(LIB_DIR, name + ".so")
+    objs, procs = [], []
+    od = os.path.join(LIB_DIR, "_" + name)
+    os.makedirs(od, exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(od, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-w"] + \
+              [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs)
+    shutil.rmtree(od, ignore_errors=True)
+    return out
+
+
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # python -m kuiperllama_amd.build --variant exp_ts128 KH_ATTN_MIN_TS=128
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build_lib(force="--force" in sys.argv, verbose=True))
 
 
 ADAPTER_TEST_SRC = os.path.normpath(os.path.join(_PKG, "..", "tests", "cpp", "test_adapter.cpp"))

@@ -199,10 +199,17 @@ static inline int attn_num_splits(int cache_len) {
   if (ns > KH_ATTN_MAX_NS) ns = KH_ATTN_MAX_NS;
   return ns;
 }
-// workspace for the split merge: [heads] int tickets | [heads*NS*2] (M,L) | [heads*NS*hs] o
+// workspace for the split merge: [heads] int tickets | [heads*NS*2] (M,L) | [heads*NS*hs] o, every region rounded up
+// to 16 bytes: k_wo_comb's CombStager reads `o` with dwordx4 loads (head counts that are not a multiple of four -
+// Qwen2.5-0.5B: 14 - used to leave it 8 bytes off), and a per-token workspace stride stays 16-byte aligned
+__host__ __device__ static inline size_t attn_ws_cnt_words(int heads) { return ((size_t)heads + 3) & ~(size_t)3; }
+__host__ __device__ static inline size_t attn_ws_ml_words(int heads, int ns) {
+  return ((size_t)heads * ns * 2 + 3) & ~(size_t)3;
+}
 static inline size_t attn_ws_bytes(int heads, int head_size, int ns) {
-  return ns <= 1 ? 0
-                 : (size_t)heads * sizeof(int) + (size_t)heads * ns * (2 + head_size) * sizeof(float);
+  if (ns <= 1) return 0;
+  const size_t words = attn_ws_cnt_words(heads) + attn_ws_ml_words(heads, ns) + (size_t)heads * ns * head_size;
+  return ((words + 3) & ~(size_t)3) * sizeof(float);
 }
 
 // number of splits that own timesteps at position `pos` (uniform over the grid)
@@ -228,8 +235,8 @@ __host__ __device__ static inline AttnSplitWs attn_ws_carve(void* ws, int heads,
                                                              int ns) {
   AttnSplitWs w;
   w.cnt = (int*)ws;
-  w.ml = (float*)(w.cnt + heads);
-  w.o = w.ml + (size_t)heads * ns * 2;
+  w.ml = (float*)(w.cnt + attn_ws_cnt_words(heads));
+  w.o = w.ml + attn_ws_ml_words(heads, ns);
   (void)head_size;
   return w;
 }
@@ -418,6 +425,37 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Publication of a split's partial and the hand-over to the last arriver, two forms:
+//  * default - the guide's G16 R1 form ("sc1 stores AND sc1 loads", MI355X_MICROARCH.md, correctness boundaries):
+//    every storing wave drains its write-through stores (s_waitcnt vmcnt(0)), barrier, one lane takes a relaxed
+//    agent-scope ticket; the last arriver reads the partials with agent-scope (sc1) loads, which are served past
+//    its L1.  No buffer_wbl2, no buffer_inv: 1-2 us less on the 4 k-32 k positions.  It relies on
+//    gfx950 behaviour that the HIP memory model does not spell out: relaxed agent stores are write-through,
+//    vmcnt(0) means they are acknowledged at the device coherence point, and an sc1 load is not served from a
+//    stale line.  tests/test_ops_gpu.py::test_mha_decode_split_merge_stress hammers it (uneven load, every XCD,
+//    warm readers, thousands of launches, every word checked);
+//  * fenced - KH_FLAG_ATTN_MERGE_FENCED / hook KH_ATTN_FENCED=1: the formally ordered form, release fence before
+//    the ticket and acquire fence in the last arriver (buffer_wbl2 sc1 / buffer_inv sc1), for a part, a compiler or
+//    a partition mode where the above has not been verified.
+__device__ __forceinline__ void attn_publish_barrier(bool fenced) {
+  if (fenced) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop the wait behind buffer_wbl2 (guide G16)
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void attn_acquire(bool fenced) {  // in the last arriver, before the merge (uniform)
+  if (fenced) {
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+  }
+}
+
 // One workgroup = (head h, split s) of a grid of heads*NS workgroups.  ws may be null iff NS==1.
 // defer: leave the partial in the workspace and return, whatever nact is (the consumer combines).
 // Returns true in the workgroup that wrote the head's final output.
@@ -426,7 +464,7 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
                                                       const float* v_base, int kv_stride, int hs,
                                                       int pos, float* out_h, float* smem, int h,
                                                       int s, int NS, AttnSplitWs ws, int NSW = 0,
-                                                      bool defer = false) {
+                                                      bool defer = false, bool fenced = false) {
   if (NSW <= 0) NSW = NS;  // slot stride of the workspace (>= NS)
   const int tid = threadIdx.x;
   const int nT = pos + 1;
@@ -464,13 +502,13 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
     st_agent(&ws.ml[slot * 2], M);
     st_agent(&ws.ml[slot * 2 + 1], L);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
-  __syncthreads();
+  attn_publish_barrier(fenced);
   int* flag = (int*)smem;  // red[] is free again after the barriers inside attn_fast_partial
   if (tid == 0)
     flag[0] = __hip_atomic_fetch_add(&ws.cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (flag[0] != nact - 1) return false;  // not the last arriver
+  attn_acquire(fenced);
   // ---- last arriver: merge every split's partial (agent-scope loads inside) ------------------------
   if (tid < hs) {
     out_h[tid] = attn_merge_splits(ws, h, tid, hs, nact, NSW);
@@ -641,7 +679,7 @@ template <int G, int KVM>
 __device__ __forceinline__ void attn_group_decode(const float* q_g, const float* k_base,
                                                   const float* v_base, int kv_stride, int hs,
                                                   int pos, float* out_g, float* smem, int g, int s,
-                                                  int NS, int NSW, AttnSplitWs ws) {
+                                                  int NS, int NSW, AttnSplitWs ws, bool fenced) {
   const int tid = threadIdx.x;
   const int nT = pos + 1;
   const int TS = attn_split_len(nT, NS);
@@ -666,14 +704,14 @@ __device__ __forceinline__ void attn_group_decode(const float* q_g, const float*
       st_agent(&ws.ml[slot * 2 + 1], L);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
-  __syncthreads();
+  attn_publish_barrier(fenced);
   int* flag = (int*)smem;
   if (tid == 0)
     flag[0] = __hip_atomic_fetch_add(&ws.cnt[g * KVM], 1, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (flag[0] != nact - 1) return;  // not the last arriver
+  attn_acquire(fenced);
   if (mine) out_g[(size_t)j * hs + e] = attn_merge_splits(ws, h, e, hs, nact, NSW);
   if (tid == 0)
     __hip_atomic_store(&ws.cnt[g * KVM], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -695,6 +733,7 @@ struct KhAttnArgs {
   int nsplit_g;            // GQA long-context path: kv_heads * nsplit_g workgroups (0 = off)
   int t_long;              // the group path runs when pos + 1 >= t_long
   int defer;               // per-head path: leave the split partials (also a single one) for k_wo_comb
+  int fenced;              // in-launch merge with release / acquire fences (see attn_publish_barrier)
   // prefill (kh_prefill.h): gridDim.y tokens per launch, token t at position pos + t, its q /
   // out rows tok_stride floats apart, its split workspace ws_tok_bytes apart (decode: y = 1)
   int tok_stride;
@@ -723,7 +762,8 @@ __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem
   attn_head_decode_fast<G>(
       a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
       a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, smem, h, s, a.nsplit,
-      attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), a.ws_stride, a.defer != 0);
+      attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), a.ws_stride, a.defer != 0,
+      a.fenced != 0);
 }
 
 // KVM = 0: per-head workgroups only.  KVM = kv_mul > 1: per-head workgroups at short contexts,
@@ -760,7 +800,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(KhAttnArgs a, int hos
                               a.vcache_layer + head_off, a.kv_dim, a.head_size, pos,
                               a.out + (size_t)g * KVM * a.head_size, (float*)smem_raw, g, s,
                               a.nsplit_g, a.ws_stride,
-                              attn_ws_carve(a.ws, a.kv_heads * KVM, a.head_size, a.ws_stride));
+                              attn_ws_carve(a.ws, a.kv_heads * KVM, a.head_size, a.ws_stride), a.fenced != 0);
   }
 }
 

@@ -11,6 +11,7 @@
 
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 
 #include "../../include/kuiper_hip.h"
@@ -19,14 +20,21 @@ extern char** environ;
 
 namespace {
 std::mutex g_mu;
-std::map<std::string, std::string>& table() {
-  static std::map<std::string, std::string> t = [] {
-    std::map<std::string, std::string> m;
+// Values are interned and never freed: a pointer handed out by dbg() / kh_debug_get() stays valid for the life of
+// the process, whatever another thread sets or clears meanwhile (std::set nodes do not move; the pool grows by
+// one string per DISTINCT value ever set - a handful).
+const std::string* intern(const std::string& v) {
+  static std::set<std::string> pool;
+  return &*pool.insert(v).first;
+}
+std::map<std::string, const std::string*>& table() {
+  static std::map<std::string, const std::string*> t = [] {
+    std::map<std::string, const std::string*> m;
     for (char** e = environ; e && *e; ++e) {
       if (strncmp(*e, "KH_", 3) != 0) continue;
       const char* eq = strchr(*e, '=');
       if (!eq) continue;
-      m.emplace(std::string(*e, (size_t)(eq - *e)), std::string(eq + 1));
+      m.emplace(std::string(*e, (size_t)(eq - *e)), intern(std::string(eq + 1)));
     }
     return m;
   }();
@@ -35,13 +43,13 @@ std::map<std::string, std::string>& table() {
 }  // namespace
 
 namespace khm {
-// Value of a hook, or nullptr when it is not set.  The pointer stays valid until the same key is set again.
+// Value of a hook, or nullptr when it is not set.  The pointer stays valid for the life of the process (interned).
 const char* dbg(const char* key) {
   if (!key) return nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
   auto& t = table();
   auto it = t.find(key);
-  return it == t.end() ? nullptr : it->second.c_str();
+  return it == t.end() ? nullptr : it->second->c_str();
 }
 }  // namespace khm
 
@@ -50,7 +58,7 @@ extern "C" int kh_debug_set(const char* key, const char* value) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto& t = table();
   if (value)
-    t[key] = value;
+    t[key] = intern(value);
   else
     t.erase(key);
   return KH_OK;

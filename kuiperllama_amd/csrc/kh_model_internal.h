@@ -53,6 +53,7 @@ struct kh_model {
   int attn_ws_stride = 1;   // split slots per head in attn_ws
   int attn_t_long = 1 << 30;
   int attn_wg = KH_WG;
+  bool attn_fenced = false;  // KH_FLAG_ATTN_MERGE_FENCED / KH_ATTN_FENCED: fences around the in-launch split merge
   bool attn_defer = false;  // variant 1 exists: split partials combined by kh_fused.h::k_wo_comb
   int attn_defer_max = 0;   // ... up to this many active splits (more: the in-launch merge is as fast or faster)
   int step_var = 0;         // variant the launch_* helpers use right now (set by launch_step_fused / profile)
@@ -72,6 +73,8 @@ struct kh_model {
   bool pg_launch_failed = false;
   int32_t* h_words_pin = nullptr;  // pinned mirror of d_words (stop-token check, final copy-out)
   int32_t* h_forced_pin = nullptr; // pinned staging of d_forced [seq_cap + 1]: the upload needs no host sync
+  int forced_hwm = 0;              // entries of d_forced that may differ from -1 (the last generate's upload)
+  bool forced_in_flight = false;   // a generate returned before its final stream sync: h_forced_pin may be under DMA
   // near-tie report (kh_model_first_sample): logits of the first sampled step of the last generate with a prefill
   float* first_logits = nullptr;  // [vocab], allocated on first use
   int first_pos = -1;             // -1: the last generate had no prefill phase

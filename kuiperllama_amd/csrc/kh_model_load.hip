@@ -270,6 +270,10 @@ int finish_create(kh_model* m) {
   }
   // step variant 1 - time splits merged by k_wo_comb instead of a last arriver (kh_attn.h, kh_fused.h) -
   // needs wo's in-register staging (dim <= 16 floats per thread) and heads * 16 factor slots per pass
+  {
+    const char* e = dbg("KH_ATTN_FENCED");
+    m->attn_fenced = (m->opts.flags & KH_FLAG_ATTN_MERGE_FENCED) != 0 || (e && e[0] == '1');
+  }
   m->attn_defer = m->attn_ns > 1 && !(m->opts.flags & KH_FLAG_ATTN_MERGE_IN_LAUNCH) && !dbg_off("KH_ATTN_DEFER") &&
                   comb_supported(c.dim, c.head_num, c.head_size, m->sh_wo.wg);
   {

@@ -212,6 +212,7 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   a.nsplit_g = m->step_var != 0 ? 0 : m->attn_ns_g;
   a.t_long = m->attn_t_long;
   a.defer = m->step_var == 1 ? 1 : 0;
+  a.fenced = m->attn_fenced ? 1 : 0;
   a.tok_stride = 0;
   a.ws_tok_bytes = 0;
   return a;
@@ -489,6 +490,8 @@ int ensure_seq_cap(kh_model* m, int n) {
   if ((rc = dalloc(&m->d_words, (size_t)n + 1)) != KH_OK) return rc;
   // forced[i] = -1 (0xFFFFFFFF): every position sampled, until a generate uploads its prompt
   KH_CHECK_HIP(hipMemsetAsync(m->d_forced, 0xFF, sizeof(int32_t) * ((size_t)n + 1), m->stream));
+  m->forced_hwm = 0;
+  m->forced_in_flight = false;
   m->seq_cap = n;
   // the graph captured pointers/capacity: rebuild
   destroy_step_graphs(m);
@@ -701,14 +704,21 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   // hipHostMalloc inside the step loop's event bracket stalled the first 20-step run behind a 5-step one by 0.3 ms)
   if ((rc = ensure_pinned_words(m, m->seq_cap)) != KH_OK) return rc;
   // forced[i] = token fed at position i while inside the prompt, -1 afterwards.  Staged in the model's pinned
-  // buffer: the upload is ordered before the steps by the stream and needs no host-side wait (every generate ends
-  // with a stream sync, so the buffer is never refilled under a copy in flight); only the first total_steps + 1
-  // entries are read by this run
+  // buffer: the upload is ordered before the steps by the stream and needs no host-side wait.  A generate that
+  // returned early on an error may have left its upload in flight: the buffer is refilled only behind a stream
+  // sync in that case (forced_in_flight; free when the previous call ended normally - it synchronised itself).
+  // Only the first total_steps + 1 entries are written; whatever an earlier, longer run left beyond them goes back
+  // to -1 (time_step / profile_step at deeper positions must not feed a stale prompt token).
   {
+    if (m->forced_in_flight) KH_CHECK_HIP(hipStreamSynchronize(m->stream));
     const int nf = total_steps + 1 <= m->seq_cap + 1 ? total_steps + 1 : m->seq_cap + 1;
     for (int i = 0; i < nf; ++i) m->h_forced_pin[i] = i < n_prompt ? h_prompt[i] : -1;
+    m->forced_in_flight = true;
     KH_CHECK_HIP(hipMemcpyAsync(m->d_forced, m->h_forced_pin, (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice,
                                 m->stream));
+    if (m->forced_hwm > nf)
+      KH_CHECK_HIP(hipMemsetAsync(m->d_forced + nf, 0xFF, (size_t)(m->forced_hwm - nf) * sizeof(int32_t), m->stream));
+    m->forced_hwm = nf;
   }
   const int n_forced = m->seq_cap + 1;
   if (exec == KH_EXEC_GRAPH) {
@@ -718,21 +728,24 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     // reaches position 256
     // ... and each has been LAUNCHED once: the first launch of an instantiated graph costs ~0.1-0.3 ms on this
     // runtime even after hipGraphUpload (a 20-step run behind a 5-step warm-up: 1012 tok/s, every later one 1028 on
-    // the same model instance).  The dry launches start at position 0 and write cache rows / words 0 .. 14 that this
-    // very call rewrites (generate always starts at position 0); skipped when the cache is shorter than that.
+    // the same model instance).  Every dry launch starts at position 0 and only graphs of at most total_steps steps
+    // are launched, so they write cache rows / words 0 .. n-1 and read forced[1 .. n] - rows this very call rewrites
+    // (generate always starts at position 0) and entries it has just uploaded; K/V rows beyond total_steps that an
+    // earlier predict / prefill left are not touched.  Longer graphs pay their first launch when a longer run comes.
     bool fresh[4] = {false, false, false, false};
     hipGraphExec_t ge = nullptr;
     for (int n = 1, k = 0; n <= KH_GRAPH_STEPS; n *= 2, ++k) {
       fresh[k] = m->sg[0][k].e == nullptr;
       if ((rc = step_graph_n(m, n_forced, 0, n, &ge)) != KH_OK) return rc;
     }
-    if ((fresh[0] || fresh[1] || fresh[2] || fresh[3]) && c.cache_len >= 2 * KH_GRAPH_STEPS &&
-        m->seq_cap >= 2 * KH_GRAPH_STEPS) {
-      set_state(m, h_prompt[0], 0);
-      for (int k = 3; k >= 0; --k)
-        if (fresh[k]) KH_CHECK_HIP(hipGraphLaunch(m->sg[0][k].e, m->stream));
-      KH_CHECK_HIP(hipStreamSynchronize(m->stream));
-    }
+    bool dry = false;
+    for (int k = 3, n = KH_GRAPH_STEPS; k >= 0; --k, n >>= 1)
+      if (fresh[k] && n <= total_steps) {
+        set_state(m, h_prompt[0], 0);
+        KH_CHECK_HIP(hipGraphLaunch(m->sg[0][k].e, m->stream));
+        dry = true;
+      }
+    if (dry) KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   }
 
   // prompt phase: the tokens that are only fed (positions 0 .. n_prompt-2).  KH_PREFILL selects how:
@@ -740,13 +753,14 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   //   "gemv"         B-token VALU kernels: K/V rows bit-identical to the token-by-token ones
   //   "gemm"         fp32-MFMA GEMM prefill: rows equal to fp32 round-off (tolerance, NOT bit-identity:
   //                  greedy tokens can differ from the token-by-token path at near-ties)
-  //   unset          "gemm" from KH_PG_MIN_TOKENS fed-only tokens on, "gemv" below that
+  //   unset          KH_FLAG_PREFILL_EXACT: "gemv" always; otherwise "gemm" from KH_PG_MIN_TOKENS fed-only tokens
+  //                  on, "gemv" below that
   // any other value is an error (KH_ERR_INVALID_ARG), not a silent choice.
   int start = 0;
   KH_CHECK_HIP(hipEventRecord(m->ev0, m->stream));
   if (n_prompt - 1 >= 2 && n_prompt - 1 < total_steps) {
     const char* e = dbg("KH_PREFILL");
-    bool want_gemm = n_prompt - 1 >= KH_PG_MIN_TOKENS, want_gemv = true;
+    bool want_gemm = n_prompt - 1 >= KH_PG_MIN_TOKENS && !(m->opts.flags & KH_FLAG_PREFILL_EXACT), want_gemv = true;
     if (e && *e) {
       if (!strcmp(e, "0") || !strcmp(e, "token")) want_gemm = want_gemv = false;
       else if (!strcmp(e, "gemv")) want_gemm = false;
@@ -865,6 +879,7 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     n_out = stop_at >= 0 ? stop_at : total_steps;
     memcpy(h_words, m->h_words_pin, sizeof(int32_t) * (size_t)n_out);
   }
+  m->forced_in_flight = false;  // both branches above end with a stream sync
   if (h_elapsed_ms) KH_CHECK_HIP(hipEventElapsedTime(h_elapsed_ms, m->ev0, m->ev1));
   *n_words = n_out;
   return KH_OK;

@@ -493,6 +493,10 @@ static int launch_mha_fast(const int32_t* d_pos, int32_t pos, int32_t head_num,
   a.nsplit_g = nsplit_g;
   a.t_long = t_long;
   a.defer = 0;  // operator level: the launch leaves the final output
+  {
+    const char* e = khm::dbg("KH_ATTN_FENCED");
+    a.fenced = (e && e[0] == '1') ? 1 : 0;
+  }
   a.tok_stride = 0;
   a.ws_tok_bytes = 0;
   launch_attn_decode(a, pos, KH_WG_MAX, s);

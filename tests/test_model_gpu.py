@@ -944,6 +944,27 @@ def test_prefill_api_modes_and_errors(gpu):
         assert np.array_equal(kv["token"][l][1], kv["gemv"][l][1])
         np.testing.assert_allclose(kv["gemm"][l][0], kv["token"][l][0], rtol=0, atol=KV_ATOL_GEMM)
         np.testing.assert_allclose(kv["gemm"][l][1], kv["token"][l][1], rtol=0, atol=KV_ATOL_GEMM)
+    # which prompt path generate() takes is part of the API: default = GEMM from 16 fed-only tokens on (tolerance
+    # parity), KH_FLAG_PREFILL_EXACT = the bit-identical B-token path whatever the length; first_sample() reports it
+    prompt = toks[:30]
+    m_def = KuiperModel.from_device_image(img_d, spec)
+    m_exact = KuiperModel.from_device_image(img_d, spec, flags=_ffi.KH_FLAG_PREFILL_EXACT)
+    m_def.generate(prompt, 36, exec="graph")
+    assert m_def.first_sample()["prefill_mode"] == "gemm"
+    w_exact, _ = m_exact.generate(prompt, 36, exec="graph")
+    assert m_exact.first_sample()["prefill_mode"] == "gemv"
+    os.environ["KH_PREFILL"] = "token"  # the reference's own prompt phase, one forward pass per prompt token
+    try:
+        w_token, _ = m_def.generate(prompt, 36, exec="graph")
+    finally:
+        del os.environ["KH_PREFILL"]
+    assert m_def.first_sample() is None
+    assert w_exact == w_token
+    assert np.array_equal(m_exact.logits(), m_def.logits())  # bit-identical to the token-by-token run, to the last step
+    m_def.generate(prompt[:8], 12, exec="graph")  # short prompts take the bit-identical path in both
+    assert m_def.first_sample()["prefill_mode"] == "gemv"
+    m_def.close()
+    m_exact.close()
     m = KuiperModel.from_device_image(img_d, spec)
     with pytest.raises(_ffi.KhError) as ei:
         m.prefill_gemm([1, 2, 3], spec.seq_len - 1)  # runs past the cache

@@ -462,6 +462,65 @@ def test_mha_decode_gqa_group_path(gpu, oracle, heads, kv_heads, hs, monkeypatch
     assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
 
 
+@pytest.mark.parametrize("heads,kv_heads,hs,tlong", [(32, 32, 128, 0), (32, 8, 64, 300), (14, 2, 64, 0)])
+def test_mha_decode_split_merge_stress(gpu, heads, kv_heads, hs, tlong, monkeypatch):
+    """The in-launch merge of time splits hands (M, L, o) partials from the split workgroups to the last arriver
+    WITHOUT fences by default: write-through (sc1) stores, drained vmcnt, a relaxed agent ticket, sc1 loads
+    (csrc/kh_attn.h: attn_publish_barrier; MI355X guide G16 R1).  A stale read there would silently corrupt the
+    attention output, so the form is hammered: 600 back-to-back launches on one workspace, the query vector and
+    the position changing with every launch (so every slot's contents change and a stale line of the PREVIOUS
+    launch is a wrong answer), 16 ... 2 splits per head on the per-head path and the GQA group path (threshold
+    lowered), all workgroups of all XCDs taking turns as last arriver, while a second stream saturates the memory
+    system with copies (uneven load: the workgroups' arrival order is scrambled).  Every output word of every
+    launch must equal, bit for bit, what the FENCED form (KH_ATTN_FENCED=1: release / acquire fences around the
+    same merge) produced for that (query, position) on an idle GPU."""
+    from kuiperllama_amd import ops
+    if tlong:
+        monkeypatch.setenv("KH_ATTN_TLONG", str(tlong))
+    seq = 4096
+    rng = np.random.default_rng(heads * 7 + hs)
+    kv_dim, kv_mul, dim = kv_heads * hs, heads // kv_heads, heads * hs
+    kcd = dev(rng.standard_normal((1, seq, kv_dim)).astype(np.float32), gpu)
+    vcd = dev(rng.standard_normal((1, seq, kv_dim)).astype(np.float32), gpu)
+    NQ = 12
+    qs = dev(rng.standard_normal((NQ, dim)).astype(np.float32), gpu)
+    poss = [4095, 300, 2047, 1023, 3071, 511, 4000, 767, 1500, 2560, 3583, 256]
+    cases = [(i % NQ, poss[(i * 5) % len(poss)]) for i in range(NQ * len(poss))]
+    cases = list(dict.fromkeys(cases))
+    ws = ops.mha_decode_workspace(heads, hs, seq, gpu)
+    d_pos = {p: torch.tensor([p], dtype=torch.int32, device=gpu) for p in poss}
+    # reference: the fenced form, one launch at a time on an idle device
+    monkeypatch.setenv("KH_ATTN_FENCED", "1")
+    want = {}
+    for qi, p in cases:
+        out = torch.full((dim,), float("nan"), device=gpu)
+        ops.mha_decode(d_pos[p], heads, 0, seq, kv_dim, kv_mul, hs, out, qs[qi], kcd, vcd, ws)
+        torch.cuda.synchronize()
+        want[(qi, p)] = out.clone()
+    monkeypatch.delenv("KH_ATTN_FENCED")
+    # the default (fence-free) form under load
+    N = 600
+    outs = torch.full((N, dim), float("nan"), device=gpu)
+    noise_a = torch.empty(64 << 20, dtype=torch.float32, device=gpu)  # 256 MB
+    noise_b = torch.empty_like(noise_a)
+    side = torch.cuda.Stream()
+    stop = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(100):
+            noise_b.copy_(noise_a)
+            noise_a.copy_(noise_b)
+    order = [cases[(i * 7) % len(cases)] for i in range(N)]
+    for i, (qi, p) in enumerate(order):
+        ops.mha_decode(d_pos[p], heads, 0, seq, kv_dim, kv_mul, hs, outs[i], qs[qi], kcd, vcd, ws)
+    torch.cuda.synchronize()
+    bad = 0
+    for i, key in enumerate(order):
+        if not torch.equal(outs[i], want[key]):
+            bad += 1
+    assert bad == 0, f"{bad} of {N} launches differ from the fenced merge (stale or torn partials)"
+    assert int(host(ws[: heads * 4].view(torch.int32)).sum()) == 0  # tickets re-armed
+
+
 @pytest.mark.parametrize("layer_index", [15, 33])
 def test_mha_decode_real_stride_deep_layer(gpu, oracle, layer_index):
     """Llama-3.2-1B attention geometry at the REAL cache stride (seq_len = 131072 rows per layer),

@@ -17,6 +17,8 @@ from kuiperllama_amd.model import KuiperModel  # noqa: E402
 names = sys.argv[1:] or ["llama3.2-1b"]
 dev = torch.device("cuda:0")
 POS = (63, 255, 256, 511, 1023, 2047, 4094, 4095, 4096, 8191, 16383, 32767, 32768, 131071)
+if os.environ.get("AB_POS"):  # e.g. AB_POS=63,127,191,255
+    POS = tuple(int(x) for x in os.environ["AB_POS"].split(","))
 for name in names:
     spec = binfmt.PRESETS[name]
     img = binfmt.synth_image(spec, seed=1234, device=dev)
