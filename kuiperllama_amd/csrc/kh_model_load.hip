@@ -14,6 +14,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -33,13 +34,31 @@ int ilog2_exact(int v) {
 }
 
 // Host image (typically the mmap of a .bin file: pageable, possibly not yet paged in) -> HBM.
-// A plain hipMemcpy from pageable memory is staged by the driver in small pieces; here two
-// pinned 64 MiB buffers are filled by a helper thread (page-in + memcpy) while the previous
-// buffer is in flight on the copy engine, so disk/page-cache reads, the host memcpy and the
-// PCIe transfer overlap.  Matters for the 27 GB fp32 7B image of the 8-replica config.
+// A plain hipMemcpy from pageable memory is staged by the driver in small pieces.  Here a ring of four pinned
+// 32-MiB buffers is filled by a team of host threads - each chunk is cut into one slice per thread, so the page
+// faults and the memcpy of ONE chunk run on all of them (a single filler thread moves 6-9 GB/s: rounds 1-4
+// uploaded at 14-17 GB/s) - while up to three earlier chunks are in flight on the copy engine.  The main thread
+// only sequences: chunk c is handed to the DMA engine when all of its slices are staged, and its buffer goes back
+// to the fillers when that transfer has completed.  Matters for the 27 GB fp32 7B image of the 8-replica config.
+int upload_threads() {
+  long n = sysconf(_SC_NPROCESSORS_ONLN);
+  // a cgroup CPU quota makes the online count a lie (256 logical CPUs seen, 16 granted on the GPU boxes)
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = 0, period = 0;
+    char q[32] = {0};
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      quota = atoll(q);
+      if (quota > 0 && quota / period < n) n = (long)(quota / period);
+    }
+    fclose(f);
+  }
+  n /= 2;
+  return n < 1 ? 1 : (n > 8 ? 8 : (int)n);
+}
 hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t stream,
                           float* ms_out) {
-  const size_t CH = (size_t)64 << 20;
+  constexpr int NB = 4;
+  const size_t CH = (size_t)32 << 20;
   const auto t0 = std::chrono::steady_clock::now();
   if (n <= CH) {
     hipError_t e = hipMemcpy(d_dst, h_src, n, hipMemcpyHostToDevice);
@@ -47,35 +66,53 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
       *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return e;
   }
-  char* pin[2] = {nullptr, nullptr};
-  hipEvent_t done[2] = {nullptr, nullptr};
+  char* pin[NB] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t done[NB] = {nullptr, nullptr, nullptr, nullptr};
   hipError_t e = hipSuccess;
-  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+  for (int i = 0; i < NB && e == hipSuccess; ++i) {
     e = hipHostMalloc((void**)&pin[i], CH, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
   }
   if (e == hipSuccess) {
     const size_t nchunks = (n + CH - 1) / CH;
-    auto fill = [&](size_t c) {  // helper-thread body: page-in + copy chunk c into its pinned buffer
-      const size_t off = c * CH, len = off + CH <= n ? CH : n - off;
-      memcpy(pin[c & 1], h_src + off, len);
+    const int NT = upload_threads();
+    std::vector<std::atomic<int>> filled(nchunks);  // slices of chunk c staged
+    for (auto& f : filled) f.store(0, std::memory_order_relaxed);
+    std::atomic<long> released{NB};   // chunks [0, released) may be staged: their buffers are free
+    std::atomic<bool> abort_{false};
+    auto worker = [&](int w) {
+      for (size_t c = 0; c < nchunks; ++c) {
+        while ((long)c >= released.load(std::memory_order_acquire)) {
+          if (abort_.load(std::memory_order_relaxed)) return;
+          std::this_thread::yield();
+        }
+        const size_t off = c * CH, len = off + CH <= n ? CH : n - off;
+        // slice w of the chunk, 4-KiB granular so that two threads never fault the same page
+        const size_t per = ((len + NT - 1) / NT + 4095) & ~(size_t)4095;
+        const size_t s0 = (size_t)w * per, s1 = s0 + per < len ? s0 + per : len;
+        if (s0 < len) memcpy(pin[c % NB] + s0, h_src + off + s0, s1 - s0);
+        filled[c].fetch_add(1, std::memory_order_release);
+      }
     };
-    std::thread filler(fill, (size_t)0);
+    std::vector<std::thread> team;
+    for (int w = 0; w < NT; ++w) team.emplace_back(worker, w);
     for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
-      filler.join();  // chunk c is staged
+      while (filled[c].load(std::memory_order_acquire) < NT) std::this_thread::yield();
       const size_t off = c * CH, len = off + CH <= n ? CH : n - off;
-      e = hipMemcpyAsync(d_dst + off, pin[c & 1], len, hipMemcpyHostToDevice, stream);
-      if (e == hipSuccess) e = hipEventRecord(done[c & 1], stream);
-      if (c + 1 < nchunks) {
-        // the other buffer was last used by chunk c-1: wait for that transfer, then refill it
-        if (c >= 1 && e == hipSuccess) e = hipEventSynchronize(done[(c + 1) & 1]);
-        filler = std::thread(fill, c + 1);
+      e = hipMemcpyAsync(d_dst + off, pin[c % NB], len, hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) e = hipEventRecord(done[c % NB], stream);
+      // chunk c + 1 reuses the buffer of chunk c + 1 - NB: hand it back once that transfer is through
+      if (c + 1 >= (size_t)NB && c + 1 < nchunks && e == hipSuccess) {
+        e = hipEventSynchronize(done[(c + 1) % NB]);
+        released.store((long)c + 2, std::memory_order_release);
       }
     }
-    if (filler.joinable()) filler.join();
+    if (e != hipSuccess) abort_.store(true);
+    released.store((long)nchunks + NB, std::memory_order_release);
+    for (auto& t : team) t.join();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
   }
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NB; ++i) {
     if (done[i]) (void)hipEventDestroy(done[i]);
     if (pin[i]) (void)hipHostFree(pin[i]);
   }
@@ -83,6 +120,38 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
     *ms_out = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return e;
 }
+
+// sin / cos table of the RoPE, rows [0, CL): computed on the host with libm exactly as the CPU backend does
+// (cpu/rope_kernel.cpp:4-16), so the fp32 table is bit-identical to the CPU reference's down to row 131071.  Every
+// entry is independent, so the rows are cut among a few threads (16.8 M libm calls for a 131072-row cache: 0.25 s on
+// one core, a third of a model load), and the job runs beside the weight upload (SinCosJob).
+struct SinCosJob {
+  std::vector<float> s, c;
+  std::vector<std::thread> team;
+  void start(size_t CL, int head_size, float theta) {
+    const size_t n = CL * (size_t)head_size;
+    s.resize(n);
+    c.resize(n);
+    std::vector<float> freq((size_t)head_size);
+    for (int d = 0; d < head_size; ++d) freq[d] = 1.0f / powf(theta, (float)d / (float)head_size);
+    const int NT = CL >= 4096 ? upload_threads() : 1;
+    for (int w = 0; w < NT; ++w)
+      team.emplace_back([this, CL, head_size, freq, w, NT] {
+        const size_t p0 = CL * (size_t)w / NT, p1 = CL * (size_t)(w + 1) / NT;
+        for (size_t p = p0; p < p1; ++p)
+          for (int d = 0; d < head_size; ++d) {
+            const float val = (float)p * freq[d];
+            s[p * head_size + d] = sinf(val);
+            c[p * head_size + d] = cosf(val);
+          }
+      });
+  }
+  void join() {
+    for (auto& t : team) t.join();
+    team.clear();
+  }
+  ~SinCosJob() { join(); }
+};
 
 // ---- weight table ------------------------------------------------------------------------
 // Byte offsets are relative to the weight data (= file bytes after the header), mirroring
@@ -216,7 +285,7 @@ size_t expected_weight_bytes(const kh_config& c) {
   return q + (q / (size_t)c.group_size) * sizeof(float) + (V * dim + 2 * L * dim + dim) * sizeof(float);
 }
 
-int finish_create(kh_model* m) {
+int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   const kh_config& c = m->cfg;
   int rc;
   if ((rc = build_weight_table(m)) != KH_OK) return rc;
@@ -298,19 +367,16 @@ int finish_create(kh_model* m) {
   // (cpu/rope_kernel.cpp:4-16) so the fp32 table is bit-identical to the CPU reference's,
   // then uploaded once.  (kh_sincos_cache_f32 is the on-device twin of sin_cos_cache_calc_cu.)
   {
+    SinCosJob local;
+    SinCosJob* job = sincos;  // started beside the weight upload by the callers that upload; here otherwise
+    if (!job) {
+      local.start(CL, c.head_size, c.rope_theta);
+      job = &local;
+    }
+    job->join();
     const size_t n = CL * c.head_size;
-    std::vector<float> hs_(n), hc_(n);
-    std::vector<float> freq((size_t)c.head_size);
-    for (int d = 0; d < c.head_size; ++d)
-      freq[d] = 1.0f / powf(c.rope_theta, (float)d / (float)c.head_size);
-    for (size_t p = 0; p < CL; ++p)
-      for (int d = 0; d < c.head_size; ++d) {
-        const float val = (float)p * freq[d];
-        hs_[p * c.head_size + d] = sinf(val);
-        hc_[p * c.head_size + d] = cosf(val);
-      }
-    KH_CHECK_HIP(hipMemcpy(m->sin_cache, hs_.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    KH_CHECK_HIP(hipMemcpy(m->cos_cache, hc_.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    KH_CHECK_HIP(hipMemcpy(m->sin_cache, job->s.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    KH_CHECK_HIP(hipMemcpy(m->cos_cache, job->c.data(), n * sizeof(float), hipMemcpyHostToDevice));
   }
   if ((rc = configure_step_kernels(m)) != KH_OK) return rc;
   KH_CHECK_HIP(hipEventCreate(&m->ev0));
@@ -420,6 +486,8 @@ extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbyte
     *out = nullptr;
     return KH_ERR_FORMAT;
   }
+  SinCosJob sincos;  // the RoPE table is computed on host threads while the weights travel
+  sincos.start((size_t)m->cfg.cache_len, m->cfg.head_size, m->cfg.rope_theta);
   hipError_t e = hipMalloc((void**)&m->arena, need);
   if (e == hipSuccess) {
     m->owns_arena = true;
@@ -429,12 +497,13 @@ extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbyte
     e = upload_chunked(m->arena, (const char*)h_image + hdr, need, m->stream, &m->load_ms);
   }
   if (e != hipSuccess) {
+    sincos.join();
     kh_model_destroy(m);
     *out = nullptr;
     return (int)e;
   }
   m->cfg.weight_bytes = (int64_t)need;
-  rc = finish_create(m);
+  rc = finish_create(m, &sincos);
   if (rc != KH_OK) {
     kh_model_destroy(m);
     m = nullptr;
@@ -459,6 +528,9 @@ extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* 
     close(fd);
     return KH_ERR_IO;
   }
+  // one sequential pass over the whole file: read ahead aggressively, drop behind
+  (void)madvise(data, (size_t)st.st_size, MADV_SEQUENTIAL);
+  (void)madvise(data, (size_t)st.st_size, MADV_WILLNEED);
   const int rc = kh_model_create_from_host_image(data, (size_t)st.st_size, opts, out);
   munmap(data, (size_t)st.st_size);
   close(fd);

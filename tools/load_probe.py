@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""kh_model_create_from_file on an image in /dev/shm: whole-call and upload-only GB/s, three loads.
+usage: tools/load_probe.py [workload]   (run on the GPU box)"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from kuiperllama_amd import binfmt  # noqa: E402
+from kuiperllama_amd.model import KuiperModel  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "llama3.2-1b"
+spec = binfmt.PRESETS[name]
+img = binfmt.synth_image(spec, seed=1234, device=torch.device("cuda:0"))
+path = f"/dev/shm/kh_probe_{os.getpid()}.bin"
+img.cpu().numpy().tofile(path)
+n = int(img.numel())
+del img
+torch.cuda.empty_cache()
+try:
+    for i in range(3):
+        t0 = time.perf_counter()
+        m = KuiperModel.from_file(path, spec)
+        wall = time.perf_counter() - t0
+        up = m.load_ms
+        words, _ = m.generate([1, 263], 8)
+        m.close()
+        print(json.dumps({"workload": name, "GB": round(n / 1e9, 2), "create_ms": round(wall * 1e3, 1),
+                          "GB/s": round(n / wall / 1e9, 1), "upload_ms": round(up, 1),
+                          "upload_GB/s": round(n / up / 1e6, 1), "other_ms": round(wall * 1e3 - up, 1),
+                          "words": words[:4]}), flush=True)
+finally:
+    os.unlink(path)
