@@ -179,9 +179,17 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 #define KH_ATTN_UB 4
 #endif
 #ifndef KH_ATTN_MIN_TS
-#define KH_ATTN_MIN_TS 256  // timesteps per split before a second split is opened
+#define KH_ATTN_MIN_TS 256  // timesteps a head keeps in ONE split; also the split quantum of the GQA group path
 #endif
 #define KH_ATTN_MAX_NS 16
+// Per-head path: split quantum 1 << ts_shift timesteps, chosen per geometry (attn_ts_shift_for).  A split streams
+// 2 * quantum * head_size * 4 bytes of K/V from ONE workgroup, and splitting costs a merge (2.3-3 us on Llama-2-7B,
+// in the wo kernel or in the last arriver): a head stays in one split up to KH_ATTN_MIN_TS timesteps whatever the
+// quantum, beyond that the quantum that measured best keeps a split at about 128 KiB - 256 timesteps at head size
+// 64 (Llama-3.2-1B: 128 loses 2 % at position 2047 and 2.5 % at 4095, profiles/r4_attn_min_ts.txt), 128 at head
+// size 128 (Llama-2-7B: -3.6 % per token at position 383, -3.9 % at 511, -2 % at 1023, -0.6 % at 2047;
+// profiles/r5_attn_7b_ts.txt).  Hook KH_ATTN_TS = 64 | 128 | 256 overrides.
+#define KH_ATTN_TS_SHIFT_MAX 8
 #define KH_ATTN_TLONG_DEFAULT 4096  // pos + 1 from which GQA models switch to the group path
 #ifndef KH_ATTN_MAX_NS_G
 // splits per KV group (the last arriver merges them all).  16 / 24 / 48 / 64 measured: 48 / 64 (two workgroups per CU) far worse
@@ -192,9 +200,19 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 static inline size_t attn_fast_lds_bytes(int head_size, int wg = KH_WG) {
   return (size_t)(8 + 8 + (wg / KH_WAVE) * head_size) * sizeof(float);
 }
+static inline int attn_ts_shift_for(int head_size) {
+  if (const char* e = khm::dbg("KH_ATTN_TS")) {
+    const int v = atoi(e);
+    if (v == 64) return 6;
+    if (v == 128) return 7;
+    if (v == 256) return 8;
+  }
+  return head_size >= 128 ? 7 : 8;
+}
 // splits per head carried by the grid for a cache of `cache_len` rows
-static inline int attn_num_splits(int cache_len) {
-  int ns = (cache_len + KH_ATTN_MIN_TS - 1) / KH_ATTN_MIN_TS;
+static inline int attn_num_splits(int cache_len, int ts_shift = KH_ATTN_TS_SHIFT_MAX) {
+  if (cache_len <= KH_ATTN_MIN_TS) return 1;
+  int ns = (cache_len + (1 << ts_shift) - 1) >> ts_shift;
   if (ns < 1) ns = 1;
   if (ns > KH_ATTN_MAX_NS) ns = KH_ATTN_MAX_NS;
   return ns;
@@ -213,17 +231,33 @@ static inline size_t attn_ws_bytes(int heads, int head_size, int ns) {
 }
 
 // number of splits that own timesteps at position `pos` (uniform over the grid)
-__host__ __device__ static inline int attn_split_len(int nT, int NS) {
+__host__ __device__ static inline int attn_split_len(int nT, int NS, int ts_shift = KH_ATTN_TS_SHIFT_MAX) {
   int TS = (nT + NS - 1) / NS;
   TS = (TS + 63) & ~63;
-  return TS < KH_ATTN_MIN_TS ? KH_ATTN_MIN_TS : TS;
+  return TS < (1 << ts_shift) ? (1 << ts_shift) : TS;
 }
-__host__ __device__ static inline int attn_active_splits(int pos, int NS) {
-  // every split is KH_ATTN_MIN_TS long up to NS of them: a shift, no division (this runs on the device too, between
-  // the arrival of the position and the first address of k_wo_comb's staging)
-  if (pos + 1 <= NS * KH_ATTN_MIN_TS) return (pos + KH_ATTN_MIN_TS) / KH_ATTN_MIN_TS;
-  const int TS = attn_split_len(pos + 1, NS);
-  return (pos + 1 + TS - 1) / TS;
+// Split length TS and number of splits that own timesteps (uniform over the grid) at position `pos`:
+//   pos + 1 <= 256 (and a quantum below 256): one split - nothing to merge inside the headline window;
+//   up to NS quanta: every split is one quantum long - shifts, no division (this runs on the device too, between
+//   the arrival of the position and the first address of the attention launch / of k_wo_comb's staging);
+//   beyond: NS splits of ceil((pos + 1) / NS) timesteps rounded up to 64.
+__host__ __device__ static inline void attn_split_geometry(int pos, int NS, int ts_shift, int& TS, int& nact) {
+  const int nT = pos + 1;
+  if (ts_shift < KH_ATTN_TS_SHIFT_MAX && nT <= KH_ATTN_MIN_TS) {
+    TS = KH_ATTN_MIN_TS;
+    nact = 1;
+  } else if (nT <= (NS << ts_shift)) {
+    TS = 1 << ts_shift;
+    nact = (nT + TS - 1) >> ts_shift;
+  } else {
+    TS = attn_split_len(nT, NS, ts_shift);
+    nact = (nT + TS - 1) / TS;
+  }
+}
+__host__ __device__ static inline int attn_active_splits(int pos, int NS, int ts_shift = KH_ATTN_TS_SHIFT_MAX) {
+  int TS, nact;
+  attn_split_geometry(pos, NS, ts_shift, TS, nact);
+  return nact;
 }
 
 struct AttnSplitWs {
@@ -464,20 +498,13 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
                                                       const float* v_base, int kv_stride, int hs,
                                                       int pos, float* out_h, float* smem, int h,
                                                       int s, int NS, AttnSplitWs ws, int NSW = 0,
-                                                      bool defer = false, bool fenced = false) {
+                                                      bool defer = false, bool fenced = false,
+                                                      int ts_shift = KH_ATTN_TS_SHIFT_MAX) {
   if (NSW <= 0) NSW = NS;  // slot stride of the workspace (>= NS)
   const int tid = threadIdx.x;
   const int nT = pos + 1;
-  // up to NS * 256 timesteps every split is 256 long (attn_split_len's minimum): no division between the arrival of
-  // the position and the first address; longer contexts take the general form (same values)
   int TS, nact;
-  if (nT <= NS * KH_ATTN_MIN_TS) {
-    TS = KH_ATTN_MIN_TS;
-    nact = (nT + KH_ATTN_MIN_TS - 1) / KH_ATTN_MIN_TS;  // a shift
-  } else {
-    TS = attn_split_len(nT, NS);
-    nact = (nT + TS - 1) / TS;  // uniform over the grid
-  }
+  attn_split_geometry(pos, NS, ts_shift, TS, nact);  // uniform over the grid; shifts only at the positions that matter
   if (s >= nact) return false;
   const int t_begin = s * TS;
   const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
@@ -732,6 +759,7 @@ struct KhAttnArgs {
   int ws_stride;           // split slots per head in the workspace (>= nsplit, >= nsplit_g)
   int nsplit_g;            // GQA long-context path: kv_heads * nsplit_g workgroups (0 = off)
   int t_long;              // the group path runs when pos + 1 >= t_long
+  int ts_shift;            // per-head path: log2 of the split quantum (attn_ts_shift_for)
   int defer;               // per-head path: leave the split partials (also a single one) for k_wo_comb
   int fenced;              // in-launch merge with release / acquire fences (see attn_publish_barrier)
   // prefill (kh_prefill.h): gridDim.y tokens per launch, token t at position pos + t, its q /
@@ -763,7 +791,7 @@ __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem
       a.q + (size_t)h * a.head_size, a.kcache_layer + head_off, a.vcache_layer + head_off,
       a.kv_dim, a.head_size, pos, a.out + (size_t)h * a.head_size, smem, h, s, a.nsplit,
       attn_ws_carve(a.ws, a.kv_heads * a.kv_mul, a.head_size, a.ws_stride), a.ws_stride, a.defer != 0,
-      a.fenced != 0);
+      a.fenced != 0, a.ts_shift);
 }
 
 // KVM = 0: per-head workgroups only.  KVM = kv_mul > 1: per-head workgroups at short contexts,
@@ -827,12 +855,13 @@ static inline bool attn_group_supported(int head_size, int kv_mul, int wg) {
 // t_long_override < 0: default policy - models with few KV heads (Qwen2.5-0.5B: 2) cannot fill the chip
 // with (group, split) workgroups and stay per-head; 0 = never; > 0 = that threshold.
 struct AttnPlan {
-  int ns, ns_g, stride, t_long;
+  int ns, ns_g, stride, t_long, ts_shift;
 };
 static inline AttnPlan attn_plan(int head_num, int kv_mul, int head_size, int cache_len, int wg,
                                  int t_long_override) {
   AttnPlan p;
-  p.ns = head_size > 32 ? attn_num_splits(cache_len) : 1;
+  p.ts_shift = attn_ts_shift_for(head_size);
+  p.ns = head_size > 32 ? attn_num_splits(cache_len, p.ts_shift) : 1;
   p.ns_g = 0;
   p.stride = p.ns;
   p.t_long = 1 << 30;
@@ -894,7 +923,7 @@ static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStr
         const int n = attn_active_splits(p, a.nsplit_g);
         if (n > group_splits) group_splits = n;
       } else {
-        const int n = attn_active_splits(p, a.nsplit);
+        const int n = attn_active_splits(p, a.nsplit, a.ts_shift);
         if (n > head_splits) head_splits = n;
       }
     }

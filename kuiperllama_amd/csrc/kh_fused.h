@@ -238,6 +238,7 @@ struct KhCombArgs {
   const float* o;         // [heads, nsw, hs] unnormalised outputs
   const int32_t* d_pos;
   int ns;                 // time splits per head carried by the attention grid (<= KH_ATTN_MAX_NS)
+  int ts_shift;           // log2 of the split quantum (KhAttnArgs::ts_shift)
   int nsw;                // split slots per head in the workspace
   int heads, hs;
 };
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_wo_comb(const KhWoCombArgs a) 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.g.M);
-  const int nact = attn_active_splits(*a.cb.d_pos, a.cb.ns);
+  const int nact = attn_active_splits(*a.cb.d_pos, a.cb.ns, a.cb.ts_shift);
   float* fl = red + 3 * KH_WAVES_MAX;
   // The o loads travel beside the first weight tile where both fit the 128 registers of a
   // 4-waves-per-SIMD launch (4 splits x 2 float4 or 2 x 4 per batch).  A 64-register tile (fp32 U = 8) or

@@ -53,6 +53,7 @@ struct kh_model {
   int attn_ws_stride = 1;   // split slots per head in attn_ws
   int attn_t_long = 1 << 30;
   int attn_wg = KH_WG;
+  int attn_ts_shift = 8;     // log2 of the per-head split quantum (kh_attn.h::attn_ts_shift_for)
   bool attn_fenced = false;  // KH_FLAG_ATTN_MERGE_FENCED / KH_ATTN_FENCED: fences around the in-launch split merge
   bool attn_defer = false;  // variant 1 exists: split partials combined by kh_fused.h::k_wo_comb
   int attn_defer_max = 0;   // ... up to this many active splits (more: the in-launch merge is as fast or faster)

@@ -333,6 +333,7 @@ int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   {
     const AttnPlan ap = attn_plan(c.head_num, c.kv_mul, c.head_size, c.cache_len, m->attn_wg, attn_tlong_hook());
     m->attn_ns = ap.ns;
+    m->attn_ts_shift = ap.ts_shift;
     m->attn_ns_g = ap.ns_g;
     m->attn_ws_stride = ap.stride;
     m->attn_t_long = ap.t_long;

@@ -211,6 +211,7 @@ KhAttnArgs fill_attn(kh_model* m, int l) {
   // per-head-only instantiation, whose register count leaves room for two 512-thread workgroups per CU
   a.nsplit_g = m->step_var != 0 ? 0 : m->attn_ns_g;
   a.t_long = m->attn_t_long;
+  a.ts_shift = m->attn_ts_shift;
   a.defer = m->step_var == 1 ? 1 : 0;
   a.fenced = m->attn_fenced ? 1 : 0;
   a.tok_stride = 0;
@@ -274,6 +275,7 @@ void launch_wo(kh_model* m, int l) {
     a.cb.o = ws.o;
     a.cb.d_pos = m->d_pos;
     a.cb.ns = m->attn_ns;
+    a.cb.ts_shift = m->attn_ts_shift;
     a.cb.nsw = m->attn_ws_stride;
     a.cb.heads = c.head_num;
     a.cb.hs = c.head_size;
@@ -380,7 +382,7 @@ int step_variant(const kh_model* m, int pos_lo, int pos_hi) {
   (void)pos_lo;
   if (pos_hi < KH_ATTN_MIN_TS) return 0;         // pos + 1 <= 256 everywhere: one split
   if (pos_hi + 1 >= m->attn_t_long) return 0;    // some step runs the group path
-  if (m->attn_defer && attn_active_splits(pos_hi, m->attn_ns) <= m->attn_defer_max) return 1;
+  if (m->attn_defer && attn_active_splits(pos_hi, m->attn_ns, m->attn_ts_shift) <= m->attn_defer_max) return 1;
   // Variant 2: the merge stays in the attention launch, but every step of the range is below the group path's
   // threshold, so the launch uses the per-head-only instantiation.  The one that also carries the group path needs
   // 138+ registers (two K/V batches in flight for kv_mul heads): one 512-thread workgroup per CU, which cost the 512

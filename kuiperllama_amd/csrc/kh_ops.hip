@@ -492,6 +492,7 @@ static int launch_mha_fast(const int32_t* d_pos, int32_t pos, int32_t head_num,
   a.ws_stride = ws_stride;
   a.nsplit_g = nsplit_g;
   a.t_long = t_long;
+  a.ts_shift = attn_ts_shift_for(head_size);
   a.defer = 0;  // operator level: the launch leaves the final output
   {
     const char* e = khm::dbg("KH_ATTN_FENCED");
@@ -565,14 +566,15 @@ extern "C" int kh_plan_attention(int32_t head_num, int32_t kv_mul, int32_t head_
   mha_decode_geometry(head_num, kv_mul, head_size, seq_len, &ns, &ns_g, &stride, &tl);
   const bool grp = ns_g > 0 && pos + 1 >= tl;
   const int NS = grp ? ns_g : ns;
-  const int nact = attn_active_splits(pos, NS);
+  int nact, TS;
+  attn_split_geometry(pos, NS, grp ? KH_ATTN_TS_SHIFT_MAX : attn_ts_shift_for(head_size), TS, nact);
   out8[0] = ns;
   out8[1] = ns_g;
   out8[2] = stride;
   out8[3] = tl;
   out8[4] = grp ? 1 : 0;
   out8[5] = nact;
-  out8[6] = attn_split_len(pos + 1, NS);
+  out8[6] = TS;
   out8[7] = (grp ? head_num / kv_mul : head_num) * nact;
   return KH_OK;
 }

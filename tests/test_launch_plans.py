@@ -137,4 +137,23 @@ def test_attention_plan_and_split_geometry(monkeypatch):
             want_len = max(256, (-(-nt // n) + 63) // 64 * 64)
             assert p["split_len"] == want_len and p["active_splits"] == -(-nt // want_len), (seq, pos, p)
             assert p["active_splits"] <= n
+    # head size 128 (Llama-2-7B): one split up to 256 timesteps, then a 128-timestep quantum (a split then streams the
+    # 128 KiB that 256 timesteps of a 64-wide head are); KH_ATTN_TS overrides the quantum
+    assert _ffi.plan_attention(32, 1, 128, 2048, 0)["ns"] == 16
+    for pos, (n_want, len_want) in {63: (1, 256), 255: (1, 256), 256: (3, 128), 383: (3, 128), 384: (4, 128),
+                                    1023: (8, 128), 2047: (16, 128)}.items():
+        p = _ffi.plan_attention(32, 1, 128, 2048, pos)
+        assert (p["active_splits"], p["split_len"], p["workgroups"]) == (n_want, len_want, 32 * n_want), (pos, p)
+    ns = _ffi.plan_attention(32, 1, 128, 9000, 0)["ns"]
+    for pos in range(0, 9000):
+        p = _ffi.plan_attention(32, 1, 128, 9000, pos)
+        nt = pos + 1
+        want_len = 256 if nt <= 256 else max(128, (-(-nt // ns) + 63) // 64 * 64)
+        assert p["split_len"] == want_len and p["active_splits"] == -(-nt // want_len) <= ns, (pos, p)
+    monkeypatch.setenv("KH_ATTN_TS", "256")
+    assert _ffi.plan_attention(32, 1, 128, 2048, 383)["active_splits"] == 2
+    monkeypatch.setenv("KH_ATTN_TS", "64")
+    assert _ffi.plan_attention(32, 4, 64, 131072, 383)["active_splits"] == 6
+    assert _ffi.plan_attention(32, 4, 64, 131072, 255)["active_splits"] == 1
+    monkeypatch.delenv("KH_ATTN_TS")
 
