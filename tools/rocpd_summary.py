@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--workload", default="llama3.2-1b")
     ap.add_argument("--commit", default=os.environ.get("KH_COMMIT", ""),
                     help="commit the counters were collected on (stamped into pmc_traffic.json)")
-    ap.add_argument("--command", default="tools/profile_round4.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
+    ap.add_argument("--command", default="tools/profile_round5.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
                                          "--kernel-trace -- python tools/pmc_workload.py <workload> --steps 8")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
@@ -78,7 +78,8 @@ def main():
             if not ours(name) or cnt != counter:
                 continue
             pmc_rows.append([short(name), cnt, n, f"{avg:.3f}", f"{mn:.3f}", f"{mx:.3f}"])
-            key = short(name).split("<")[0].replace("k_", "")
+            # k_ffn13_ring / k_cls_ring are the LDS-DMA ring forms of the same launches: same key as the kernel they replace
+            key = short(name).split("<")[0].replace("k_", "").replace("_ring", "")
             t = traffic.setdefault(f"{a.workload}:{key}", {})
             if counter == "FETCH_SIZE":
                 t["read_bytes"] = avg * 1024 * 2  # gfx950: FETCH_SIZE counts 128-B requests as 64 B
