@@ -239,7 +239,11 @@ int kh_model_write_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows, c
 /* demo/main.cpp:5-47 generate(): prompt fed one token per step without sampling, then
  * greedy decode, `total_steps` forward passes in total; h_words receives the reference's
  * `words` vector.  No stop-token check (see kh_model_generate_until).  *h_elapsed_ms = wall
- * time of the step loop measured with HIP events on the model stream. */
+ * time of the step loop measured with HIP events on the model stream.
+ * A generate starts a NEW sequence at position 0 and owns the cache rows [0, max(total_steps, 8)): with
+ * KH_EXEC_GRAPH, the first call after model creation (or after a longer run than any before grew the step
+ * buffers) launches each freshly captured step graph once from position 0 before the timed loop - rows and words
+ * 0 .. 7 - so that no later run pays a graph's first launch; rows beyond that range are never touched. */
 int kh_model_generate(kh_model* m, const int32_t* h_prompt, int32_t n_prompt,
                       int32_t total_steps, int32_t exec, int32_t* h_words, int32_t* n_words,
                       float* h_elapsed_ms);

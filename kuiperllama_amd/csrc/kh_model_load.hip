@@ -26,6 +26,18 @@ using namespace khm;
 
 namespace {
 
+// KH_LOAD_DEBUG=1: wall-clock of the phases of a model creation on stderr
+struct PhaseClock {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  const bool on = dbg("KH_LOAD_DEBUG") != nullptr;
+  void lap(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[kh load] %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
   int s = 0;
@@ -69,10 +81,12 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
   char* pin[NB] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t done[NB] = {nullptr, nullptr, nullptr, nullptr};
   hipError_t e = hipSuccess;
+  PhaseClock pc;
   for (int i = 0; i < NB && e == hipSuccess; ++i) {
     e = hipHostMalloc((void**)&pin[i], CH, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
   }
+  pc.lap("pinned staging ring");
   if (e == hipSuccess) {
     const size_t nchunks = (n + CH - 1) / CH;
     const int NT = upload_threads();
@@ -111,6 +125,7 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
     released.store((long)nchunks + NB, std::memory_order_release);
     for (auto& t : team) t.join();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    pc.lap("staged upload");
   }
   for (int i = 0; i < NB; ++i) {
     if (done[i]) (void)hipEventDestroy(done[i]);
@@ -288,6 +303,7 @@ size_t expected_weight_bytes(const kh_config& c) {
 int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   const kh_config& c = m->cfg;
   int rc;
+  PhaseClock pc;
   if ((rc = build_weight_table(m)) != KH_OK) return rc;
   m->gshift = c.is_quant ? ilog2_exact(c.group_size) : 0;
   const size_t CL = (size_t)c.cache_len;
@@ -302,6 +318,7 @@ int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   KH_ALLOC(m->h3, (size_t)c.hidden_dim);
   KH_ALLOC(m->logits, (size_t)c.vocab_size);
   KH_ALLOC(m->score, (size_t)c.head_num * CL);
+  pc.lap("weight table + small buffers");
   KH_ALLOC(m->kcache, (size_t)c.layer_num * CL * c.kv_dim);
   KH_ALLOC(m->vcache, (size_t)c.layer_num * CL * c.kv_dim);
   KH_ALLOC(m->sin_cache, CL * c.head_size);
@@ -360,6 +377,7 @@ int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   KH_ALLOC(m->part_val, (size_t)m->nparts);
   KH_ALLOC(m->part_idx, (size_t)m->nparts);
 #undef KH_ALLOC
+  pc.lap("caches, tables, plans, workspace");
   KH_CHECK_HIP(hipMemsetAsync(m->kcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
   KH_CHECK_HIP(hipMemsetAsync(m->vcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
   KH_CHECK_HIP(hipMemsetAsync(m->d_pos, 0, sizeof(int32_t), m->stream));
@@ -375,15 +393,18 @@ int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
       job = &local;
     }
     job->join();
+    pc.lap("wait for the RoPE table threads");
     const size_t n = CL * c.head_size;
     KH_CHECK_HIP(hipMemcpy(m->sin_cache, job->s.data(), n * sizeof(float), hipMemcpyHostToDevice));
     KH_CHECK_HIP(hipMemcpy(m->cos_cache, job->c.data(), n * sizeof(float), hipMemcpyHostToDevice));
   }
+  pc.lap("RoPE table upload");
   if ((rc = configure_step_kernels(m)) != KH_OK) return rc;
   KH_CHECK_HIP(hipEventCreate(&m->ev0));
   KH_CHECK_HIP(hipEventCreate(&m->ev1));
   if ((rc = ensure_seq_cap(m, 256)) != KH_OK) return rc;
   KH_CHECK_HIP(hipStreamSynchronize(m->stream));
+  pc.lap("kernel attributes, events, sync");
   return KH_OK;
 }
 
@@ -489,22 +510,37 @@ extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbyte
   }
   SinCosJob sincos;  // the RoPE table is computed on host threads while the weights travel
   sincos.start((size_t)m->cfg.cache_len, m->cfg.head_size, m->cfg.rope_theta);
+  PhaseClock pc;
   hipError_t e = hipMalloc((void**)&m->arena, need);
-  if (e == hipSuccess) {
-    m->owns_arena = true;
-    m->arena_bytes = need;
-    // weights go up once, in file order, into one arena (the reference cudaMallocs and copies
-    // every tensor separately: tensor.cpp:104-119)
-    e = upload_chunked(m->arena, (const char*)h_image + hdr, need, m->stream, &m->load_ms);
-  }
+  pc.lap("arena hipMalloc");
   if (e != hipSuccess) {
     sincos.join();
     kh_model_destroy(m);
     *out = nullptr;
     return (int)e;
   }
+  m->owns_arena = true;
+  m->arena_bytes = need;
   m->cfg.weight_bytes = (int64_t)need;
+  // Weights go up once, in file order, into one arena (the reference cudaMallocs and copies every tensor
+  // separately: tensor.cpp:104-119) - on a helper thread, while this thread builds everything that does not read
+  // them: the weight table (addresses only), the KV cache and activation buffers (hipMalloc of 8.6 GB of cache for
+  // a 131072-row Llama-3.2-1B context takes 0.1-0.4 s on some boxes: as long as the upload itself), launch plans,
+  // the RoPE table's upload.  Both sides enqueue on the model's stream; nothing here launches a kernel.
+  hipError_t eu = hipSuccess;
+  const int dev = m->opts.device;
+  std::thread uploader([&] {
+    eu = hipSetDevice(dev);
+    if (eu == hipSuccess) eu = upload_chunked(m->arena, (const char*)h_image + hdr, need, m->stream, &m->load_ms);
+  });
   rc = finish_create(m, &sincos);
+  uploader.join();
+  if (rc == KH_OK && eu != hipSuccess) rc = (int)eu;
+  if (rc == KH_OK) {
+    const hipError_t es = hipStreamSynchronize(m->stream);
+    if (es != hipSuccess) rc = (int)es;
+  }
+  pc.lap("upload || buffers, joined");
   if (rc != KH_OK) {
     kh_model_destroy(m);
     m = nullptr;
@@ -524,6 +560,7 @@ extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* 
     close(fd);
     return KH_ERR_IO;
   }
+  PhaseClock pc;
   void* data = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
   if (data == MAP_FAILED || data == nullptr) {
     close(fd);
@@ -532,9 +569,18 @@ extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* 
   // one sequential pass over the whole file: read ahead aggressively, drop behind
   (void)madvise(data, (size_t)st.st_size, MADV_SEQUENTIAL);
   (void)madvise(data, (size_t)st.st_size, MADV_WILLNEED);
+  pc.lap("open + mmap + madvise");
   const int rc = kh_model_create_from_host_image(data, (size_t)st.st_size, opts, out);
-  munmap(data, (size_t)st.st_size);
-  close(fd);
+  pc.lap("create_from_host_image");
+  // Tearing down the page tables of a multi-GB mapping whose every page was touched costs tens of milliseconds
+  // (1.2 M PTEs for the 4.98 GB Llama-3.2-1B image: 60-80 ms measured) and nobody waits for it: a detached thread
+  // unmaps and closes while the caller already decodes.
+  const size_t len = (size_t)st.st_size;
+  std::thread([data, len, fd] {
+    munmap(data, len);
+    close(fd);
+  }).detach();
+  pc.lap("munmap handed to a helper thread");
   return rc;
 }
 

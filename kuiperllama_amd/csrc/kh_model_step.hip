@@ -730,10 +730,13 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
     // reaches position 256
     // ... and each has been LAUNCHED once: the first launch of an instantiated graph costs ~0.1-0.3 ms on this
     // runtime even after hipGraphUpload (a 20-step run behind a 5-step warm-up: 1012 tok/s, every later one 1028 on
-    // the same model instance).  Every dry launch starts at position 0 and only graphs of at most total_steps steps
-    // are launched, so they write cache rows / words 0 .. n-1 and read forced[1 .. n] - rows this very call rewrites
-    // (generate always starts at position 0) and entries it has just uploaded; K/V rows beyond total_steps that an
-    // earlier predict / prefill left are not touched.  Longer graphs pay their first launch when a longer run comes.
+    // the same model instance).  Every dry launch starts at position 0 (set_state before each one), so together they
+    // write cache rows / words 0 .. 7 and read forced[1 .. 8] - uploaded above, or -1 beyond this call's prompt:
+    // rows this very call rewrites (generate always starts a new sequence at position 0) unless total_steps < 8, in
+    // which case rows total_steps .. 7 hold the K/V of a throw-away continuation afterwards (kuiper_hip.h says so:
+    // a generate owns rows [0, max(total_steps, 8)) of the cache).  Skipped when the cache is shorter than that.
+    // (Launching only the graphs of at most total_steps steps - the first r5 form - left the 8-step graph's first
+    // launch inside the timed loop of a 20-step run behind a 5-step warm-up: 1018 instead of 1036-1042 tok/s.)
     bool fresh[4] = {false, false, false, false};
     hipGraphExec_t ge = nullptr;
     for (int n = 1, k = 0; n <= KH_GRAPH_STEPS; n *= 2, ++k) {
@@ -741,12 +744,13 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
       if ((rc = step_graph_n(m, n_forced, 0, n, &ge)) != KH_OK) return rc;
     }
     bool dry = false;
-    for (int k = 3, n = KH_GRAPH_STEPS; k >= 0; --k, n >>= 1)
-      if (fresh[k] && n <= total_steps) {
-        set_state(m, h_prompt[0], 0);
-        KH_CHECK_HIP(hipGraphLaunch(m->sg[0][k].e, m->stream));
-        dry = true;
-      }
+    if (c.cache_len >= KH_GRAPH_STEPS && m->seq_cap >= KH_GRAPH_STEPS)
+      for (int k = 3; k >= 0; --k)
+        if (fresh[k]) {
+          set_state(m, h_prompt[0], 0);
+          KH_CHECK_HIP(hipGraphLaunch(m->sg[0][k].e, m->stream));
+          dry = true;
+        }
     if (dry) KH_CHECK_HIP(hipStreamSynchronize(m->stream));
   }
 
