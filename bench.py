@@ -37,6 +37,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -183,6 +184,89 @@ def cpu_baseline(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=1
             "max_logit_err_vs_oracle": logit_check}
 
 
+def cpu_baseline_reference(spec, img_host, gpu_words, max_tokens, budget_s, min_sample_s=10.0, gpu_logits=None):
+    """The reference's OWN CPU backend, timed on this host (cpu_baseline.kind = "reference"): oracle/_ref/ref_cpu_model*
+    = the reference's model / operator classes, CPU getters and its ten CPU kernels (kuiper/source/op/kernels/cpu/*.cpp)
+    compiled where they lie in the build container, Armadillo answered by tests/cpp/ref_stubs/armadillo over numpy's
+    bundled OpenBLAS (the reference's Armadillo -> BLAS sgemv path), run on the image the GPU just decoded (written to
+    /dev/shm), same prompt, whole greedy passes of up to max_tokens steps until ~min_sample_s of decode time.  Returns
+    None when no build of the backend fits the workload (int8: the reference has no CPU int8; a flavour without a
+    build) or the binaries are absent - the caller falls back to the oracle ("port")."""
+    from kuiperllama_amd import build as kbuild
+    from oracle import oracle as O
+    flavor = kbuild.ref_cpu_flavor(spec)
+    exe = kbuild.REF_CPU_BINS.get(flavor) if flavor else None
+    if not exe or not os.path.exists(exe):
+        return None
+    nbytes = int(np.asarray(img_host).nbytes)
+    try:
+        st = os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize < nbytes + (1 << 30) or host_mem_available_gb() < 1.3 * nbytes / 1e9 + 8:
+            log(f"[bench] reference CPU backend skipped for {spec.name}: not enough /dev/shm or host memory")
+            return None
+    except OSError:
+        return None
+    tok_model = os.path.join(ROOT, "tests", "golden", "spm_llama_like.model")
+    path = f"/dev/shm/kh_bench_refcpu_{os.getpid()}.bin"
+    lpath = path + ".logits"
+    eff = O.effective_cpus()
+    prompt = ",".join(map(str, PROMPT))
+
+    def run(steps, threads, budget, logits=False):
+        cmd = [exe, path, tok_model, str(steps), prompt, str(budget)] + ([lpath] if logits else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(120.0, 6 * budget_s),
+                           env=dict(os.environ, KH_REF_BLAS_THREADS=str(threads)))
+        if r.returncode != 0:
+            raise RuntimeError(f"{os.path.basename(exe)} failed: {r.stdout[-300:]} {r.stderr[-300:]}")
+        lines = r.stdout.strip().split("\n")
+        words = [int(x) for x in lines[0].split()[1:]]
+        ms = float(lines[2].split(" steps in ")[1].split(" ms")[0])
+        return words, ms * 1e-3, lines[1].replace("blas: ", "")
+    try:
+        np.asarray(img_host).tofile(path)
+        calib = {}
+        best = None
+        for c in sorted({c for c in (eff, eff // 2, 8) if 1 <= c <= eff}, reverse=True):
+            w, sec, _ = run(4, c, 30.0)
+            calib[str(c)] = round(sec / len(w) * 1e3, 2)
+            log(f"[bench] reference CPU backend calibration: {c} BLAS threads -> {sec / len(w) * 1e3:.1f} ms/token")
+            if best is None or sec / len(w) < best[0]:
+                best = (sec / len(w), c)
+        threads = best[1]
+        t0 = time.perf_counter()
+        n, dt, passes, first_words, blas, logit_check = 0, 0.0, 0, None, None, None
+        while True:
+            want_lg = gpu_logits is not None and first_words is None
+            words, sec, blas = run(max_tokens, threads, max(1.0, budget_s - (time.perf_counter() - t0)), logits=want_lg)
+            n += len(words)
+            dt += sec
+            passes += 1
+            if first_words is None:
+                first_words = words
+                if want_lg and len(words) > gpu_logits[0]:
+                    lg = np.fromfile(lpath, dtype=np.float32).reshape(len(words), -1)[gpu_logits[0]]
+                    err = float(np.abs(lg - gpu_logits[1]).max())
+                    logit_check = {"pos": gpu_logits[0], "max_abs_err": err, "tolerance": LOGIT_TOL_F32,
+                                   "ok": bool(err <= LOGIT_TOL_F32)}
+            if dt > min(min_sample_s, budget_s) or time.perf_counter() - t0 > budget_s:
+                break
+    finally:
+        for f in (path, lpath):
+            if os.path.exists(f):
+                os.unlink(f)
+    words = first_words
+    n_cmp = min(len(words), len(gpu_words))
+    div = next((i for i in range(n_cmp) if words[i] != gpu_words[i]), None)
+    return {"value": n / dt, "unit": "tokens/s", "cores": threads, "kind": "reference", "host": host_cpu_facts(),
+            "sample": f"{n} decode steps = {passes} pass(es) over the first {len(words)} steps of the same greedy decode "
+                      f"({spec.name}, prompt {PROMPT}) by {os.path.basename(exe)}: the reference's LLama2Model / Qwen2Model "
+                      f"on kDeviceCPU over its own cpu/*.cpp kernels, {dt:.1f}s of decode time",
+            "variant": f"reference translation units ({flavor} flavour build) over tests/cpp/ref_stubs/armadillo; sgemv from {blas}",
+            "calibration_ms_per_token": calib,
+            "tokens_match_gpu": bool(n_cmp > 0 and div is None), "tokens_compared": n_cmp, "first_divergence": div,
+            "max_logit_err_vs_reference_cpu": logit_check}
+
+
 def host_cpu_facts() -> dict:
     """What the CPU baseline ran on: logical CPUs the OS shows, the cgroup quota, and what the
     process may really use (the baseline moves +-30 % between boxes with these)."""
@@ -313,7 +397,14 @@ def other_config(spec, local_rank, args, steps=128):
             budget = max(4.0, args.cpu_budget_s / 3) if big else 3.0
             img_h = img.cpu().numpy()
             try:
-                r = cpu_baseline(spec, img_h, words, 16 if big else 32, budget, min_sample_s=budget if big else 1.5)
+                r = None
+                try:
+                    r = cpu_baseline_reference(spec, img_h, words, 16 if big else 32, budget,
+                                               min_sample_s=budget if big else 1.5)
+                except Exception as e:  # noqa: BLE001
+                    log(f"[bench] reference CPU backend unavailable for {spec.name}: {e!r}")
+                if r is None:
+                    r = cpu_baseline(spec, img_h, words, 16 if big else 32, budget, min_sample_s=budget if big else 1.5)
             finally:
                 del img_h
             out["cpu_baseline"] = {k: r[k] for k in ("value", "unit", "cores", "kind", "sample", "variant", "host")}
@@ -524,8 +615,25 @@ def measure(spec, args, rank, world, local_rank, primary):
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.extras:
         if primary:
             img_h = img.cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(spec, img_h, ref_words, args.cpu_tokens, args.cpu_budget_s,
-                                               gpu_logits=gpu_logits)
+            ref = None
+            try:
+                ref = cpu_baseline_reference(spec, img_h, ref_words, args.cpu_tokens, args.cpu_budget_s,
+                                             gpu_logits=gpu_logits)
+            except Exception as e:  # noqa: BLE001  (fall back to the port, say why)
+                log(f"[bench] reference CPU backend unavailable: {e!r}")
+                out["cpu_baseline_reference_error"] = repr(e)
+            if ref is not None:
+                # the reference's own CPU backend is the reported baseline; the oracle ("port": the restatement the
+                # parity tests use) is timed beside it on a shorter sample, and carries the logit check vs the oracle
+                port = cpu_baseline(spec, img_h, ref_words, min(args.cpu_tokens, 48), max(4.0, args.cpu_budget_s / 3),
+                                    min_sample_s=4.0, gpu_logits=gpu_logits)
+                ref["port"] = {k: port[k] for k in ("value", "unit", "cores", "kind", "sample", "variant",
+                                                    "tokens_match_gpu", "tokens_compared", "max_logit_err_vs_oracle")}
+                ref["max_logit_err_vs_oracle"] = port["max_logit_err_vs_oracle"]
+                out["cpu_baseline"] = ref
+            else:
+                out["cpu_baseline"] = cpu_baseline(spec, img_h, ref_words, args.cpu_tokens, args.cpu_budget_s,
+                                                   gpu_logits=gpu_logits)
             del img_h
         elif spec.name == "llama2-7b-int8":
             try:

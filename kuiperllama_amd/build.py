@@ -181,6 +181,36 @@ def build_ref_model(qwen2: bool = False) -> str | None:
     return exe
 
 
+REF_CPU_BINS = {flavor: os.path.normpath(os.path.join(_PKG, "..", "oracle", "_ref", "ref_cpu_model" + suffix))
+                for flavor, suffix in (("default", ""), ("llama3", "_llama3"), ("qwen2", "_qwen2"))}
+
+
+def build_ref_cpu() -> dict | None:
+    """oracle/_ref/ref_cpu_model{,_llama3,_qwen2}: the reference's OWN CPU backend - its ten CPU kernels
+    (kuiper/source/op/kernels/cpu/*.cpp compiled where they lie over tests/cpp/ref_stubs/armadillo + numpy's OpenBLAS), CPU
+    getters, operator and model classes - in its three compile-time flavours (oracle/Makefile `ref_cpu`).  The checker
+    of tests/test_ref_cpu_backend.py and bench.py's timed CPU baseline (kind "reference").  Only where the reference
+    checkout exists; the binaries travel to the GPU box.  Returns {flavour: path} or None."""
+    if os.path.isdir(os.path.join(REF_ROOT, "kuiper", "include")):
+        build_lib()
+        subprocess.check_call(["make", "-s", "-C", os.path.normpath(os.path.join(_PKG, "..", "oracle")),
+                               "ref_cpu", f"KUIPER_REF={REF_ROOT}", f"HIPCC={_hipcc()}"])
+    return dict(REF_CPU_BINS) if all(os.path.exists(p) for p in REF_CPU_BINS.values()) else None
+
+
+def ref_cpu_flavor(spec) -> str | None:
+    """Which build of the reference CPU backend runs a model of this spec (its RoPE flavour / theta / eps are
+    compile-time switches: cpu/rope_kernel.cpp:3-16,43,83, cpu/rmsnorm_kernel.cpp:24-28); None: no such build."""
+    from . import binfmt
+    if spec.quant:
+        return None  # the reference has no CPU int8 path
+    key = (spec.family, spec.rope_mode, float(spec.rope_theta), float(spec.rms_eps))
+    table = {(binfmt.FAMILY_LLAMA, binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5): "default",
+             (binfmt.FAMILY_LLAMA, binfmt.ROPE_HALF, 500000.0, 1e-5): "llama3",
+             (binfmt.FAMILY_QWEN2, binfmt.ROPE_HALF, 1000000.0, 1e-6): "qwen2"}
+    return table.get(key)
+
+
 def kernel_sources_sha1() -> str:
     """sha1 over the device-code headers of the decode / prefill kernels (csrc/kh_*.h except the host-only
     kh_model_internal.h), in name order.  profiles/pmc_traffic.json is stamped with it when the PMC passes are
