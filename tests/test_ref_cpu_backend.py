@@ -139,7 +139,11 @@ def test_hip_decode_equals_reference_cpu_backend_full_size(gpu, preset, steps):
     assert words == want, next((i, a, b) for i, (a, b) in enumerate(zip(words, want)) if a != b)
     err = float(np.abs(m.logits() - lg[-1]).max())
     m.close()
-    assert err <= 4e-5, err
+    # two fp32 summation orders (OpenBLAS's sgemv blocking vs wave-strided + butterfly): each sits a few 1e-5 from the
+    # exact value on the 32-layer, 4096-wide model (tests/test_model_gpu.py bounds that one against the fp64 gold run:
+    # |HIP - oracle32| <= 3 |oracle32 - gold64|); 4e-5 as everywhere else for the other geometries
+    tol = 1e-4 if spec.dim >= 4096 else 4e-5
+    assert err <= tol, err
     assert len(set(want)) >= (5 if spec.dim < 1024 else min(20, steps // 2))  # not a fixed point (short cycles on the 15M model)
     print(f"{preset}: {steps} words equal the reference CPU backend's ({tok_s:.1f} tok/s on the host); "
           f"|logit - reference CPU| at the last step {err:.2e}")
