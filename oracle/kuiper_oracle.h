@@ -6,12 +6,17 @@
  * `cpu_baseline` leg of bench.py.
  *
  * Every function names the reference file:line it restates (paths relative to the
- * reference repo root, zjhellofss/KuiperLLama @ 2025-02-19).  The reference's C++ CPU
- * backend cannot be compiled in this environment (Armadillo, glog, CUDA headers absent —
- * SURVEY.md §8c), so this is a *port* ("kind": "port" in bench.py's cpu_baseline), pinned
- * by (a) the reference tests' integer-exact golden vectors, (b) logits produced by the
- * reference's own Python model (tools/model.py, tools/export.py) — see
- * tests/golden/make_golden.py.  The int8 path has NO CPU implementation in the reference
+ * reference repo root, zjhellofss/KuiperLLama @ 2025-02-19).  This is a *port* ("kind":
+ * "port" in bench.py), pinned by (a) the reference tests' integer-exact golden vectors,
+ * (b) logits produced by the reference's own Python model (tools/model.py, tools/export.py)
+ * — see tests/golden/make_golden.py — and, since round 5, (c) the reference's OWN C++ CPU
+ * backend: its ten CPU kernel files (cpu/<op>_kernel.cpp), operator and model classes compiled where they lie
+ * (oracle/Makefile `ref_cpu` -> oracle/_ref/ref_cpu_model*; Armadillo, absent here, is
+ * answered by tests/cpp/ref_stubs/armadillo over numpy's OpenBLAS): this oracle and that
+ * backend agree in every logit of the goldens to 2.5e-7 (tests/test_ref_cpu_backend.py).
+ * That backend, not this file, is bench.py's timed baseline ("kind": "reference") and the
+ * end-to-end checker of the full-size token parity tests; this file stays the op-level
+ * checker and the fp64-accumulate gold.  The int8 path has NO CPU implementation in the reference
  * (kernels_interfaces.cpp:54-61); ko_matmul_q8 restates the CUDA kernel
  * (cuda/matmul_kernel.cu:56-87): parity for int8 is "unpinned" beyond the exporter
  * (tools/export.py:49-73) and the torch dequantised forward.
