@@ -274,24 +274,27 @@ def test_deferred_split_merge_equals_in_launch_merge(gpu, oracle, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,hidden,vocab,heads", [(512, 1408, 501, 8), (256, 704, 1000, 4), (1024, 2816, 32000, 8)])
-def test_int8_ring_kernels_equal_register_tile_kernels(gpu, oracle, monkeypatch, dim, hidden, vocab, heads):
+@pytest.mark.parametrize("dim,hidden,vocab,heads,group", [(512, 1408, 501, 8, 64), (256, 704, 1000, 4, 64),
+                                                         (1024, 2816, 32000, 8, 64), (512, 1536, 777, 8, 128),
+                                                         (768, 2048, 1000, 12, 32)])
+def test_int8_ring_kernels_equal_register_tile_kernels(gpu, oracle, monkeypatch, dim, hidden, vocab, heads, group):
     """The int8 ffn13 / classifier launches on the LDS-DMA ring kernels (kh_fused_ring.h: weights HBM -> LDS ring
     by DMA -> ds_read, input vector staged through the DMA path, default for geometries plan_decode_ring accepts)
     against the register-tile kernels (KH_RING=0): the per-lane arithmetic is the same, so logits must be
     IDENTICAL at every position, eager and under graph replay - incl. an odd vocabulary (the classifier's last
-    row pair is one row), partial 1-KiB pieces (dim 256: 16 of 64 lanes) and several items per wave - and both sit
-    within the int8 tolerance of the oracle."""
+    row pair is one row), partial 1-KiB pieces (dim 256: 16 of 64 lanes; dim 768: a full and a half piece), groups
+    of 32 / 64 / 128 weights (one scale per lane and piece) and several items per wave - and both sit within the
+    int8 tolerance of the oracle."""
     from kuiperllama_amd import _ffi
     from kuiperllama_amd.model import KuiperModel
-    spec = binfmt.ModelSpec(dim, hidden, 2, heads, heads, vocab, 64, False, binfmt.FAMILY_LLAMA, True, 64,
-                            binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, f"ring-{dim}")
-    plan = _ffi.plan_decode_ring(dim, hidden, vocab, True)
+    spec = binfmt.ModelSpec(dim, hidden, 2, heads, heads, vocab, 64, False, binfmt.FAMILY_LLAMA, True, group,
+                            binfmt.ROPE_INTERLEAVED, 10000.0, 1e-5, f"ring-{dim}-g{group}")
+    plan = _ffi.plan_decode_ring(dim, hidden, vocab, True, group)
     assert plan["ffn13"]["slots"] == 2 and plan["cls"]["slots"] == 2
     img_d, img_h = _synth(spec, 91, gpu)
     m_ring = KuiperModel.from_device_image(img_d, spec)
     monkeypatch.setenv("KH_RING", "0")
-    assert _ffi.plan_decode_ring(dim, hidden, vocab, True)["ffn13"]["slots"] == 0
+    assert _ffi.plan_decode_ring(dim, hidden, vocab, True, group)["ffn13"]["slots"] == 0
     m_reg = KuiperModel.from_device_image(img_d, spec)
     monkeypatch.delenv("KH_RING")
     om = oracle.OracleModel.from_spec(img_h, spec)
