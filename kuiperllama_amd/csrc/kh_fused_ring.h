@@ -10,7 +10,11 @@
 #include "kh_fused.h"
 #include "kh_q8ring.h"
 
-template <int R, int MAXV, bool BLOCKED = false, int VT = 0>
+// STG: 0 = the vector staged through the DMA path (StagerDma), 1 = register loads by asm (StagerAsm)
+template <bool NORM, int MAXV, int VT, int STG>
+using RingStager = typename std::conditional<STG == 1, StagerAsm<NORM, MAXV, VT>, StagerDma<NORM, MAXV, VT>>::type;
+
+template <int R, int MAXV, bool BLOCKED = false, int VT = 0, int STG = 0>
 __global__ __launch_bounds__(1024) void k_ffn13_ring(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -22,19 +26,19 @@ __global__ __launch_bounds__(1024) void k_ffn13_ring(const KhFfn13Args a) {
   float* const h = a.h;
   const float eps = a.eps;
   const Gemv<true, 1> g(dim, a.gshift);
-  StagerDma<true, MAXV, VT> st(a.x, a.ffn_norm, xs, smem_raw + ring_lds_wraw_off(dim), dim);
+  RingStager<true, MAXV, VT, STG> st(a.x, a.ffn_norm, xs, smem_raw + ring_lds_wraw_off(dim), dim);
   auto pair = [&](int r) __attribute__((always_inline)) { return g.rows(w1, r, w3, r, s1p, s3p, dim); };
   auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane == 0) h[r] = swiglu1(s0, s1);
   };
   ring_pairs<1, R, BLOCKED>(
-      dim, a.gshift, xs, a.hidden, lane, nullptr, smem_raw + ring_lds_off(dim, true), pair,
+      dim, a.gshift, xs, a.hidden, lane, nullptr, smem_raw + ring_lds_off(dim, STG == 0), pair,
       [](int) __attribute__((always_inline)) { return NoAux{}; },
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
 }
 
-template <int R, int MAXV, bool BLOCKED = false, int VT = 0>
+template <int R, int MAXV, bool BLOCKED = false, int VT = 0, int STG = 0>
 __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
   float* const logits = a.logits;
   const float eps = a.eps;
   const Gemv<true, 1> g(dim, a.gshift);
-  StagerDma<true, MAXV, VT> st(a.x, a.final_norm, xs, smem_raw + ring_lds_wraw_off(dim), dim);
+  RingStager<true, MAXV, VT, STG> st(a.x, a.final_norm, xs, smem_raw + ring_lds_wraw_off(dim), dim);
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   auto r1_of = [&](int p) __attribute__((always_inline)) { return 2 * p + 1 < vocab ? 2 * p + 1 : 2 * p; };
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
     }
   };
   ring_pairs<1, R, BLOCKED>(
-      dim, a.gshift, xs, (vocab + 1) >> 1, lane, nullptr, smem_raw + ring_lds_off(dim, true), pair,
+      dim, a.gshift, xs, (vocab + 1) >> 1, lane, nullptr, smem_raw + ring_lds_off(dim, STG == 0), pair,
       [](int) __attribute__((always_inline)) { return NoAux{}; },
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
 }
 
 // y = W . v ; x += y (wo, w2).  The residual words x[2p], x[2p+1] come through the scalar cache (ld_uniform).
-template <int R, int MAXV, int SPLIT>
+template <int R, int MAXV, int SPLIT, int STG = 0>
 __global__ __launch_bounds__(1024) void k_gemv_res_ring(const KhGemvResArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
   f32x4* xs = (f32x4*)smem_raw;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_ring(const KhGemvResArgs a) {
   const float* const scales = a.w.scales;
   float* const x = a.x;
   const Gemv<true, 1> g(M, a.gshift);
-  StagerDma<false, MAXV> st(a.vec, nullptr, xs, nullptr, M);
+  RingStager<false, MAXV, 0, STG> st(a.vec, nullptr, xs, nullptr, M);
   auto pair = [&](int p) __attribute__((always_inline)) { return g.rows(w, 2 * p, w, 2 * p + 1, scales, scales, M); };
   struct Aux {
     float x0, x1;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_ring(const KhGemvResArgs a) {
 
 // RMSNorm(x) -> [wq|wk|wv] row pairs -> +bias -> RoPE -> q / cache row `pos` (k_qkv<true, ...>).  The epilogue
 // operands of a pair - sin, cos of its cache column and the two bias values - come through the scalar cache.
-template <int R, int MAXV, int SPLIT>
+template <int R, int MAXV, int SPLIT, int STG = 0>
 __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
   const void *wq_w = a.wq.w, *wk_w = a.wk.w, *wv_w = a.wv.w;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
   const int npq = dim >> 1, npk = kv_dim >> 1;
   const int total = npq + 2 * npk;
   const Gemv<true, 1> g(dim, a.gshift);
-  StagerDma<true, MAXV> st(a.x, a.att_norm, xs, smem_raw + ring_lds_wraw_off(dim), dim);
+  RingStager<true, MAXV, 0, STG> st(a.x, a.att_norm, xs, smem_raw + ring_lds_wraw_off(dim), dim);
   const int pos = *a.d_pos;  // scalar load: lgkmcnt, not vmcnt
 
   auto decode = [&](int p, int& which, int& r0, int& r1, int& cidx) __attribute__((always_inline)) {
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
     dst[r1] = s1;
   };
   ring_pairs<SPLIT, R, false>(
-      dim, a.gshift, xs, total, lane, red + KH_WAVES_MAX, smem_raw + ring_lds_off(dim, true), pair, auxf,
+      dim, a.gshift, xs, total, lane, red + KH_WAVES_MAX, smem_raw + ring_lds_off(dim, STG == 0), pair, auxf,
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
 }

@@ -303,8 +303,8 @@ void launch_ffn13(kh_model* m, int l) {
   a.eps = c.rms_eps;
   const bool qn = c.is_quant;
   if (m->ring.ffn_r == 2) {  // plan_ring: int8, dim a multiple of 256 floats and at most 16 per thread
-    hipLaunchKernelGGL((k_ffn13_ring<2, 4>), dim3(m->ring.ffn_grid), dim3(KH_WG), ring_lds_bytes(c.dim, true, KH_WAVES_PER_WG, 2),
-                       m->stream, a);
+    hipLaunchKernelGGL((k_ffn13_ring<2, 4, false, 0, 1>), dim3(m->ring.ffn_grid), dim3(KH_WG),
+                       ring_lds_bytes(c.dim, false, KH_WAVES_PER_WG, 2), m->stream, a);
     return;
   }
   const int kh_launch_wg = m->sh_ffn.wg;
@@ -341,8 +341,8 @@ void launch_cls(kh_model* m) {
   // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
   const bool qn = c.is_quant;
   if (m->ring.cls_r == 2) {
-    hipLaunchKernelGGL((k_cls_ring<2, 4>), dim3(m->ring.cls_grid), dim3(KH_WG), ring_lds_bytes(c.dim, true, KH_WAVES_PER_WG, 2),
-                       m->stream, a);
+    hipLaunchKernelGGL((k_cls_ring<2, 4, false, 0, 1>), dim3(m->ring.cls_grid), dim3(KH_WG),
+                       ring_lds_bytes(c.dim, false, KH_WAVES_PER_WG, 2), m->stream, a);
     return;
   }
   const int kh_launch_wg = m->sh_cls.wg;
@@ -549,19 +549,19 @@ void plan_decode_shapes(bool quant, int dim, int hidden_dim, int kv_dim, int voc
 }
 
 // The int8 ffn13 and classifier launches run on the LDS-DMA ring kernels (kh_fused_ring.h) when the geometry fits
-// them: whole 1-KiB pieces of the input vector (dim % 256 == 0), at most 16 floats of it per staging thread (the
-// MAXV = 4 staging of the 256-thread kernels, which the ring kernels reproduce bit for bit), a power-of-two group
-// of at least 16 weights (one scale per lane and piece).  Same-box A/B on Llama-2-7B int8, 32 distinct slabs per
+// them: at most 16 floats of the input vector per staging thread (the MAXV = 4 staging of the 256-thread kernels,
+// which the ring kernels reproduce bit for bit), a power-of-two group of at least 16 weights (one scale per lane and
+// piece).  Same-box A/B on Llama-2-7B int8, 32 distinct slabs per
 // graph (tools/mb_q8ring.hip, profiles/r5_int8_ring_ab.txt): ffn13 17.7-17.9 -> 16.6-16.7 us (-6...-7 %), cls
 // 24.35 -> 23.5 (-3.5 %); qkv +0.7 %, w2 -1.3 %, wo +5.8 % - those three stay on the register-tile kernels.
 // Two ring slots per wave and two 256-thread workgroups per CU measured best (deeper rings and more waves per CU
-// are slower: 3 slots +1 %, 4 slots +5 %, three workgroups per CU +6 %).  KH_RING=0 turns the ring kernels off.
+// are slower: 3 slots +1 %, 4 slots +5 %, three workgroups per CU +3 %).  KH_RING=0 turns the ring kernels off.
 void plan_ring(bool quant, int dim, int hidden_dim, int vocab_size, int group_size, kh_model::RingPlan* out) {
   *out = kh_model::RingPlan();
   if (!quant || dbg_off("KH_RING")) return;
-  if (dim % 256 != 0 || kh_stage_maxv(dim, KH_WG) != 4) return;
+  if (dim % 16 != 0 || kh_stage_maxv(dim, KH_WG) != 4) return;
   if (group_size < 16 || (group_size & (group_size - 1)) != 0 || dim % group_size != 0) return;
-  if (ring_lds_bytes(dim, true, KH_WAVES_PER_WG, 2) > 64 * 1024) return;  // no dynamic-LDS opt-in on this path
+  if (ring_lds_bytes(dim, false, KH_WAVES_PER_WG, 2) > 64 * 1024) return;  // no dynamic-LDS opt-in on this path
   auto grid_of = [](int items) {
     const int need = (items + KH_WAVES_PER_WG - 1) / KH_WAVES_PER_WG;
     return need < 512 ? need : 512;

@@ -19,9 +19,10 @@
 // bit-identical to gemv_pairs (and to the B-token prefill, kh_prefill.h) for the same SPLIT.
 //
 // The compiler does not know that the asm DMA operations occupy vmcnt slots; its own s_waitcnt for a
-// compiler-visible global LOAD would therefore drain the ring.  Hence: no vector load while the ring is live.
-// The activation vector comes through the DMA path too (StagerDma), epilogue operands (residual, sin / cos,
-// bias) through the scalar cache (ld_uniform: lgkmcnt), pointers and sizes are kernel arguments.
+// compiler-visible global LOAD would therefore drain the ring.  Hence: no vector load the compiler knows about
+// while the ring is live.  The activation vector is fetched by asm register loads with a hand-placed wait
+// (StagerAsm; StagerDma is the measured-equal alternative through the DMA path), epilogue operands (residual,
+// sin / cos, bias) through the scalar cache (ld_uniform: lgkmcnt), pointers and sizes are kernel arguments.
 // Stores are fine (nothing waits for them; vmcnt(N) with extra younger stores only over-waits).
 #pragma once
 #include <type_traits>
@@ -69,15 +70,15 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
   return *(const __attribute__((address_space(4))) float*)(unsigned long long)p;
 }
 
-// Input vector staging through the DMA path.  A VGPR-returning load and an LDS-DMA operation do not retire in
-// issue order relative to each other (measured: a vmcnt wait that covered 8 older global_load_dwordx4 behind 28
-// younger DMA operations returned before the loads had landed - every RMSNorm kernel of the first version was
-// wrong while the DMA-only ring data was right), so everything that shares the ring's vmcnt window is a DMA
-// operation: the waves of the workgroup pull the raw vector into the xs area (linear) and the norm weight into
-// its own area with 1-KiB pieces, issued BEFORE the ring prologue, and finish() waits for exactly the prologue's
-// operation count, then permutes (and normalises) in place through registers: the element -> thread mapping and
-// the arithmetic are Stager<NORM, true, MAXV>'s, so the staged vector is bit-identical.
-// Needs M % 256 == 0 (whole 1-KiB pieces); the launcher falls back to the register-tile kernels otherwise.
+// Input vector staging through the DMA path - the alternative to StagerAsm, measured equal within 0.5 % on all five
+// kernels (profiles/r5_int8_ring_ab.txt section 6) and not used by the product: the waves pull the raw vector into the
+// xs area (linear) and the norm weight into its own area with 1-KiB pieces, issued BEFORE the ring prologue, finish()
+// waits for exactly the prologue's operation count, then permutes (and normalises) in place through registers: the
+// element -> thread mapping and the arithmetic are Stager<NORM, true, MAXV>'s, so the staged vector is bit-identical.
+// Costs two more barriers, an LDS round trip and M floats of LDS for the norm weight; needs M % 256 == 0 (whole
+// 1-KiB pieces).  (It was written when the first ring version seemed to stage wrong vectors through register loads;
+// that was the microbenchmark overwriting its own reference output - tools/mb_vmcnt_order.hip shows that register
+// loads and LDS-DMA operations do retire in issue order through vmcnt, and StagerAsm is bit-identical.)
 // VT: the element -> thread mapping and the norm's reduction tree are those of a VT-thread workgroup (0: the real
 // width); threads past VT only take part in the barriers.  Lets a workgroup of any width (11 waves, ...) stage
 // exactly what the 256-thread kernels stage.
@@ -145,6 +146,75 @@ struct StagerDma {
     for (int v = 0; v < MAXV; ++v) {
       const int i = threadIdx.x + v * wgv;
       if (act && i < M4) {
+        f32x4 t = xv[v];
+        if (NORM) {
+          t.x = wv[v].x * (rs * t.x);
+          t.y = wv[v].y * (rs * t.y);
+          t.z = wv[v].z * (rs * t.z);
+          t.w = wv[v].w * (rs * t.w);
+        }
+        xs[q8_slot(i, M16)] = t;
+      }
+    }
+    __syncthreads();
+  }
+};
+
+// Input vector staging with register loads issued by inline asm (the compiler must not know them: its own wait
+// for a load it knows about counts only the loads it knows about and would drain the ring behind it).  issue()
+// requests MAXV float4 of x (and of the norm weight) per thread, exactly like Stager; finish() waits for exactly
+// those - the YOUNGER operations of the ring prologue stay in flight (loads and LDS-DMA operations retire in issue
+// order through the one vmcnt counter: tools/mb_vmcnt_order.hip) - ties every loaded register to the wait so that no
+// use can be scheduled ahead of it, and then does what Stager<NORM, true, MAXV>::finish does, in the same order.
+// Against StagerDma: no LDS detour, two barriers fewer, no raw norm-weight area in LDS.
+template <bool NORM, int MAXV, int VT = 0>
+struct StagerAsm {
+  static_assert(VT == 0, "the register staging uses the real workgroup width");
+  f32x4 xv[MAXV];
+  f32x4 wv[NORM ? MAXV : 1];
+  const float* x;
+  const float* wnorm;
+  f32x4* xs;
+  int M;
+  __device__ __forceinline__ StagerAsm(const float* x_, const float* wnorm_, f32x4* xs_, const void* /*wraw*/, int M_)
+      : x(x_), wnorm(wnorm_), xs(xs_), M(M_) {}
+  __device__ __forceinline__ void issue() {
+    const int M4 = M >> 2;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = threadIdx.x + v * kh_wg();
+      const unsigned off = (unsigned)(i < M4 ? i : 0) * 16u;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xv[v]) : "v"(off), "s"(x) : "memory");
+      if (NORM) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[v]) : "v"(off), "s"(wnorm) : "memory");
+    }
+  }
+  template <int YOUNGER>
+  __device__ __forceinline__ void finish(float eps, float* red, bool exact) {
+    if (exact)
+      wait_vm<YOUNGER>();
+    else
+      wait_vm<0>();
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      asm volatile("" : "+v"(xv[v]));
+      if (NORM) asm volatile("" : "+v"(wv[v]));
+    }
+    const int M4 = M >> 2, M16 = M >> 4;
+    float rs = 1.f;
+    if (NORM) {
+      float ss = 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const float t = fma4(xv[v], xv[v], 0.f);
+        ss += (threadIdx.x + v * kh_wg() < M4) ? t : 0.f;
+      }
+      ss = block_sum(ss, red);
+      rs = 1.0f / sqrtf(ss / (float)M + eps);
+    }
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = threadIdx.x + v * kh_wg();
+      if (i < M4) {
         f32x4 t = xv[v];
         if (NORM) {
           t.x = wv[v].x * (rs * t.x);

@@ -96,11 +96,11 @@ def test_debug_hooks_live_in_one_table_not_in_getenv(lib, monkeypatch):
     monkeypatch.delenv("KH_SHAPE_FFN")
     assert _ffi.plan_decode_shapes(2048, 8192, 512, 128256, False)["ffn13"] == base  # the mirrored key is cleared
     _ffi.debug_set("KH_SHAPE_FFN", None)
-    # the LDS-DMA ring plan: int8 geometries with whole 1-KiB pieces of the input vector take it, KH_RING=0 turns it off
+    # the LDS-DMA ring plan: int8 geometries whose input vector the 256-thread staging holds take it, KH_RING=0 turns it off
     assert _ffi.plan_decode_ring(4096, 11008, 32000, True) == {"ffn13": {"slots": 2, "grid": 512}, "cls": {"slots": 2, "grid": 512}}
     assert _ffi.plan_decode_ring(512, 1408, 501, True) == {"ffn13": {"slots": 2, "grid": 352}, "cls": {"slots": 2, "grid": 63}}
     assert _ffi.plan_decode_ring(2048, 8192, 128256, False)["ffn13"]["slots"] == 0   # fp32
-    assert _ffi.plan_decode_ring(448, 1216, 3000, True)["cls"]["slots"] == 0        # 448 floats: no whole pieces
+    assert _ffi.plan_decode_ring(448, 1216, 3000, True)["cls"] == {"slots": 2, "grid": 375}  # partial pieces are fine
     assert _ffi.plan_decode_ring(8192, 28672, 128256, True)["ffn13"]["slots"] == 0  # 32 floats per staging thread
     monkeypatch.setenv("KH_RING", "0")
     assert _ffi.plan_decode_ring(4096, 11008, 32000, True)["ffn13"]["slots"] == 0

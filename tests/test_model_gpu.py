@@ -276,13 +276,14 @@ def test_deferred_split_merge_equals_in_launch_merge(gpu, oracle, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim,hidden,vocab,heads,group", [(512, 1408, 501, 8, 64), (256, 704, 1000, 4, 64),
                                                          (1024, 2816, 32000, 8, 64), (512, 1536, 777, 8, 128),
-                                                         (768, 2048, 1000, 12, 32)])
+                                                         (768, 2048, 1000, 12, 32), (448, 1216, 3000, 7, 64)])
 def test_int8_ring_kernels_equal_register_tile_kernels(gpu, oracle, monkeypatch, dim, hidden, vocab, heads, group):
     """The int8 ffn13 / classifier launches on the LDS-DMA ring kernels (kh_fused_ring.h: weights HBM -> LDS ring
-    by DMA -> ds_read, input vector staged through the DMA path, default for geometries plan_decode_ring accepts)
+    by DMA -> ds_read, input vector staged by asm register loads beside it, default for geometries plan_decode_ring accepts)
     against the register-tile kernels (KH_RING=0): the per-lane arithmetic is the same, so logits must be
     IDENTICAL at every position, eager and under graph replay - incl. an odd vocabulary (the classifier's last
-    row pair is one row), partial 1-KiB pieces (dim 256: 16 of 64 lanes; dim 768: a full and a half piece), groups
+    row pair is one row), partial 1-KiB pieces (dim 256: 16 of 64 lanes; dim 768: a full and a half piece; dim 448: 28
+    lanes), groups
     of 32 / 64 / 128 weights (one scale per lane and piece) and several items per wave - and both sit within the
     int8 tolerance of the oracle."""
     from kuiperllama_amd import _ffi

@@ -28,6 +28,7 @@ __global__ void k_fill_f32(float* p, size_t n, uint32_t seed, float lo, float hi
 }
 
 static hipStream_t S;
+static int g_more = 0;  // argv[4]: also the work-distribution controls of the ffn13 section
 static int g_reps = 1;  // sweeps over the NL slabs per graph (argv[3]): long graphs show the sustained clock
 static float time_graph(int NL0, const std::function<void(int)>& launch) {
   hipGraph_t g; hipGraphExec_t ge;
@@ -68,6 +69,7 @@ static void report(const char* name, const char* variant, float us, double bytes
 int main(int argc, char** argv) {
   const int only = argc > 1 ? atoi(argv[1]) : -1;  // 0 ffn13, 1 cls, 2 wo, 3 w2, 4 qkv
   g_reps = argc > 3 ? atoi(argv[3]) : 1;
+  g_more = argc > 4 ? atoi(argv[4]) : 0;
   const int shift = argc > 2 ? atoi(argv[2]) : 0;  // bytes the weight / scale arrays sit off a 4-KiB boundary (a device image
                                                    // that still carries its 32-byte header puts every row 32 B off a line)
   CK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
@@ -106,31 +108,37 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_ffn13<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     report("ffn13", "shipped wg256 grid512 U4", base, bytes, true, 0);
-#define FFN_RING(RR, MV, WG, GRID) FFN_RINGX(RR, MV, WG, GRID, false, 0)
-#define FFN_RINGX(RR, MV, WG, GRID, BL, VT)                                                                               \
+#define FFN_RINGX(RR, MV, WG, GRID, BL, VT) FFN_RINGS(RR, MV, WG, GRID, BL, VT, 0)
+#define FFN_RINGS(RR, MV, WG, GRID, BL, VT, STG)                                                                          \
   do {                                                                                                                    \
-    const size_t lds = ring_lds_bytes(dim, true, (WG) / 64, RR);                                                          \
+    const size_t lds = ring_lds_off(dim, (STG) == 0) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                         \
     if (lds * (((GRID) + 255) / 256) > 160 * 1024) { printf("ffn13  ring R%d wg%d grid%d: LDS does not fit\n", RR, WG, GRID); break; } \
-    optin(k_ffn13_ring<RR, MV, BL, VT>, lds);                                                                             \
+    optin(k_ffn13_ring<RR, MV, BL, VT, STG>, lds);                                                                        \
     CK(hipMemsetAsync(o_new, 0xff, hidden * 4, S));                                                                       \
-    hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, VT>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                     \
+    hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, VT, STG>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                \
     CK(hipStreamSynchronize(S));                                                                                          \
     const bool ok = same(((WG) == 256 || (VT) == 256) ? o_ref : o_ref512, o_new, hidden, "ffn13 h");                      \
-    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, VT>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
-    char v[64]; snprintf(v, sizeof v, "ring R%d wg%d grid%d%s (%zu KB)", RR, WG, GRID, (BL) ? " blocked" : "", lds >> 10); \
+    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, VT, STG>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
+    char v[96]; snprintf(v, sizeof v, "ring R%d wg%d grid%d%s %s (%zu KB)", RR, WG, GRID, (BL) ? " blocked" : "",         \
+                         (STG) ? "x:regs" : "x:dma", lds >> 10);                                                          \
     report("ffn13", v, t, bytes, ok, base);                                                                               \
   } while (0)
-    FFN_RING(2, 4, 256, 512);
-    FFN_RING(3, 4, 256, 512);
-    FFN_RINGX(2, 4, 256, 512, true, 0);     // control: blocked mapping alone, same 8 waves per CU (43 items -> 6 rounds)
-    FFN_RINGX(2, 4, 704, 256, true, 256);   // 11 waves per CU: 43 items = 10 x 4 + 3
-    FFN_RINGX(3, 4, 704, 256, true, 256);
-    FFN_RINGX(4, 4, 704, 256, true, 256);
-    FFN_RINGX(2, 4, 704, 256, false, 256);  // control: 11 waves, interleaved mapping
-    FFN_RINGX(2, 4, 768, 256, true, 256);   // 12 waves: 43 -> 4 rounds (89.6 %)
-    FFN_RINGX(2, 4, 512, 256, true, 256);   // 8 waves, one workgroup per CU
-    FFN_RINGX(3, 4, 512, 256, true, 256);
-    FFN_RINGX(2, 4, 1024, 256, true, 256);  // 16 waves: 43 -> 3 rounds
+    FFN_RINGS(2, 4, 256, 512, false, 0, 0);
+    FFN_RINGS(3, 4, 256, 512, false, 0, 0);
+    FFN_RINGS(2, 4, 256, 512, false, 0, 1);
+    FFN_RINGS(3, 4, 256, 512, false, 0, 1);
+    FFN_RINGS(4, 4, 256, 512, false, 0, 1);
+    FFN_RINGS(2, 4, 256, 768, false, 0, 1);
+    FFN_RINGS(3, 4, 256, 768, false, 0, 1);
+    FFN_RINGS(2, 4, 256, 1024, false, 0, 1);
+    FFN_RINGS(1, 4, 256, 1024, false, 0, 1);
+    FFN_RINGS(2, 4, 512, 256, false, 0, 1);
+    FFN_RINGS(2, 4, 512, 512, false, 0, 1);
+    if (g_more) {
+      FFN_RINGX(2, 4, 256, 512, true, 0);     // control: blocked mapping alone, same 8 waves per CU (43 items -> 6 rounds)
+      FFN_RINGX(2, 4, 704, 256, true, 256);   // 11 waves per CU: 43 items = 10 x 4 + 3
+      FFN_RINGX(2, 4, 704, 256, false, 256);  // control: 11 waves, interleaved mapping
+    }
   }
   // ---------------------------------------------------------------- cls
   if (only < 0 || only == 1) {
@@ -146,30 +154,24 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_cls<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     report("cls", "shipped wg256 grid512 U4", base, bytes, true, 0);
-#define CLS_RING(RR, MV, WG, GRID)                                                                                        \
+#define CLS_RINGS(RR, MV, WG, GRID, STG)                                                                                  \
   do {                                                                                                                    \
-    const size_t lds = ring_lds_bytes(dim, true, (WG) / 64, RR);                                                          \
+    const size_t lds = ring_lds_off(dim, (STG) == 0) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                         \
     if (lds * (((GRID) + 255) / 256) > 160 * 1024) { printf("cls    ring R%d wg%d grid%d: LDS does not fit\n", RR, WG, GRID); break; } \
-    optin(k_cls_ring<RR, MV>, lds);                                                                                       \
+    optin(k_cls_ring<RR, MV, false, 0, STG>, lds);                                                                        \
     CK(hipMemsetAsync(o_new, 0xff, vocab * 4, S));                                                                        \
-    hipLaunchKernelGGL((k_cls_ring<RR, MV>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                               \
+    hipLaunchKernelGGL((k_cls_ring<RR, MV, false, 0, STG>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                \
     CK(hipStreamSynchronize(S));                                                                                          \
-    const bool ok = same((WG) == 256 ? o_ref : o_ref512, o_new, vocab, "cls logits");                                                              \
-    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_cls_ring<RR, MV>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
-    char v[64]; snprintf(v, sizeof v, "ring R%d wg%d grid%d (%zu KB LDS)", RR, WG, GRID, lds >> 10);                      \
+    const bool ok = same((WG) == 256 ? o_ref : o_ref512, o_new, vocab, "cls logits");                                     \
+    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_cls_ring<RR, MV, false, 0, STG>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
+    char v[96]; snprintf(v, sizeof v, "ring R%d wg%d grid%d %s (%zu KB)", RR, WG, GRID, (STG) ? "x:regs" : "x:dma", lds >> 10); \
     report("cls", v, t, bytes, ok, base);                                                                                 \
   } while (0)
-    CLS_RING(1, 4, 256, 768);
-    CLS_RING(2, 4, 256, 768);
-    CLS_RING(2, 4, 256, 512);
-    CLS_RING(3, 4, 256, 512);
-    CLS_RING(4, 4, 256, 512);
-    CLS_RING(1, 4, 512, 768);
-    CLS_RING(1, 4, 512, 512);
-    CLS_RING(2, 4, 512, 512);
-    CLS_RING(2, 4, 512, 256);
-    CLS_RING(3, 4, 512, 256);
-    CLS_RING(4, 4, 512, 256);
+    CLS_RINGS(2, 4, 256, 512, 0);
+    CLS_RINGS(2, 4, 256, 512, 1);
+    CLS_RINGS(3, 4, 256, 512, 1);
+    CLS_RINGS(2, 4, 256, 768, 1);
+    CLS_RINGS(2, 4, 256, 1024, 1);
   }
   // ---------------------------------------------------------------- wo (K = 4096, M = 4096, split 1) and w2 (K = 4096, M = 11008, split 2)
   for (int which = 2; which <= 3; ++which) {
@@ -193,33 +195,32 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { ship(l, o_new); });
     report(name, which == 2 ? "shipped wg256 grid512 U4 split1" : "shipped wg512 grid512 U2 split2", base, bytes, true, 0);
-#define RES_RING(RR, MV, SP, WG, GRID)                                                                                    \
+#define RES_RINGS(RR, MV, SP, WG, GRID, STG)                                                                              \
   do {                                                                                                                    \
-    const size_t lds = ring_lds_bytes(M, false, (WG) / 64, RR);                                                               \
+    const size_t lds = ring_lds_off(M, false) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                                \
     if (lds * (((GRID) + 255) / 256) > 160 * 1024) { printf("%-6s ring R%d wg%d grid%d: LDS does not fit\n", name, RR, WG, GRID); break; } \
     if (kh_stage_maxv(M, WG) != MV) break;                                                                                \
-    optin(k_gemv_res_ring<RR, MV, SP>, lds);                                                                              \
+    optin(k_gemv_res_ring<RR, MV, SP, STG>, lds);                                                                         \
     CK(hipMemcpyAsync(o_new, x0, K * 4, hipMemcpyDeviceToDevice, S));                                                     \
-    hipLaunchKernelGGL((k_gemv_res_ring<RR, MV, SP>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                      \
+    hipLaunchKernelGGL((k_gemv_res_ring<RR, MV, SP, STG>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                 \
     CK(hipStreamSynchronize(S));                                                                                          \
     const bool ok = same(o_ref, o_new, K, "x after residual");                                                            \
-    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_gemv_res_ring<RR, MV, SP>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
-    char v[64]; snprintf(v, sizeof v, "ring R%d wg%d grid%d split%d (%zu KB)", RR, WG, GRID, SP, lds >> 10);             \
+    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_gemv_res_ring<RR, MV, SP, STG>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
+    char v[96]; snprintf(v, sizeof v, "ring R%d wg%d grid%d split%d %s (%zu KB)", RR, WG, GRID, SP, (STG) ? "x:regs" : "x:dma", lds >> 10); \
     report(name, v, t, bytes, ok, base);                                                                                  \
   } while (0)
     if (which == 2) {
-      RES_RING(1, 4, 1, 256, 512);   // 2048 waves: one item (4 pieces) each
-      RES_RING(2, 4, 1, 256, 512);
-      RES_RING(4, 4, 1, 256, 512);
-      RES_RING(2, 4, 1, 256, 256);   // 1024 waves x 2 items
-      RES_RING(4, 4, 1, 256, 256);
-      RES_RING(2, 4, 1, 512, 256);
-      RES_RING(4, 4, 1, 512, 256);
+      RES_RINGS(2, 4, 1, 256, 512, 0);
+      RES_RINGS(2, 4, 1, 256, 512, 1);
+      RES_RINGS(4, 4, 1, 256, 512, 1);
+      RES_RINGS(2, 4, 1, 256, 1024, 1);
+      RES_RINGS(2, 4, 1, 512, 256, 1);
     } else {
-      RES_RING(1, 6, 2, 512, 512);   // 4096 waves = one (pair, part) item of 6 pieces each; x alone takes 44 KB of LDS
-      RES_RING(1, 6, 2, 512, 256);
-      RES_RING(2, 6, 2, 512, 256);
-      RES_RING(3, 6, 2, 512, 256);
+      RES_RINGS(2, 6, 2, 512, 256, 0);
+      RES_RINGS(2, 6, 2, 512, 256, 1);
+      RES_RINGS(3, 6, 2, 512, 256, 1);
+      RES_RINGS(1, 6, 2, 512, 512, 1);
+      RES_RINGS(2, 6, 2, 512, 512, 1);
     }
   }
   // ---------------------------------------------------------------- qkv (6144 pairs x 4096, RoPE epilogue, pos 5)
@@ -249,30 +250,25 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_qkv<true, 4, 4, 1>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     report("qkv", "shipped wg256 grid512 U4", base, bytes, true, 0);
-#define QKV_RING(RR, MV, WG, GRID)                                                                                        \
+#define QKV_RINGS(RR, MV, WG, GRID, STG)                                                                                  \
   do {                                                                                                                    \
-    const size_t lds = ring_lds_bytes(dim, true, (WG) / 64, RR);                                                             \
+    const size_t lds = ring_lds_off(dim, (STG) == 0) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                         \
     if (lds * (((GRID) + 255) / 256) > 160 * 1024) { printf("qkv    ring R%d wg%d grid%d: LDS does not fit\n", RR, WG, GRID); break; } \
-    optin(k_qkv_ring<RR, MV, 1>, lds);                                                                                    \
+    optin(k_qkv_ring<RR, MV, 1, STG>, lds);                                                                               \
     CK(hipMemsetAsync(o_new, 0xff, 3 * dim * 4, S));                                                                      \
-    hipLaunchKernelGGL((k_qkv_ring<RR, MV, 1>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                            \
+    hipLaunchKernelGGL((k_qkv_ring<RR, MV, 1, STG>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                       \
     CK(hipStreamSynchronize(S));                                                                                          \
-    const bool ok = same((WG) == 256 ? o_ref : o_ref512, o_new, 3 * dim, "q | k row | v row");                                                     \
-    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_qkv_ring<RR, MV, 1>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
-    char v[64]; snprintf(v, sizeof v, "ring R%d wg%d grid%d (%zu KB LDS)", RR, WG, GRID, lds >> 10);                      \
+    const bool ok = same((WG) == 256 ? o_ref : o_ref512, o_new, 3 * dim, "q | k row | v row");                            \
+    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_qkv_ring<RR, MV, 1, STG>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
+    char v[96]; snprintf(v, sizeof v, "ring R%d wg%d grid%d %s (%zu KB)", RR, WG, GRID, (STG) ? "x:regs" : "x:dma", lds >> 10); \
     report("qkv", v, t, bytes, ok, base);                                                                                 \
   } while (0)
-    QKV_RING(1, 4, 256, 768);
-    QKV_RING(2, 4, 256, 768);
-    QKV_RING(2, 4, 256, 512);
-    QKV_RING(3, 4, 256, 512);
-    QKV_RING(4, 4, 256, 512);
-    QKV_RING(1, 4, 512, 768);
-    QKV_RING(1, 4, 512, 512);
-    QKV_RING(2, 4, 512, 512);
-    QKV_RING(2, 4, 512, 256);
-    QKV_RING(3, 4, 512, 256);
-    QKV_RING(4, 4, 512, 256);
+    QKV_RINGS(2, 4, 256, 768, 0);
+    QKV_RINGS(2, 4, 256, 512, 1);
+    QKV_RINGS(3, 4, 256, 512, 1);
+    QKV_RINGS(2, 4, 256, 768, 1);
+    QKV_RINGS(3, 4, 256, 768, 1);
+    QKV_RINGS(2, 4, 256, 1024, 1);
   }
   return 0;
 }
