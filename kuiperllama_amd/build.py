@@ -68,10 +68,27 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-def build_variant(name: str, defines: list[str]) -> str:
+def build_variant(name: str, defines: list[str], commit: str | None = None) -> str:
     """Experiment build: kuiperllama_amd/lib/<name>.so = the library with extra -D flags (KH_LIB selects it at run
-    time, kuiperllama_amd/_ffi.py).  Used by tools/gpu_job_*.sh for same-box A/Bs of compile-time constants."""
+    time, kuiperllama_amd/_ffi.py).  Used by tools/gpu_job_*.sh for same-box A/Bs of compile-time constants.
+    `commit`: build the sources as they were at that commit (`--variant-at <commit> <name> ...`: an A/B against an
+    earlier form of a kernel without keeping the earlier form alive behind a macro)."""
     out = os.path.join(LIB_DIR, name + ".so")
+    if commit:
+        import tarfile
+        import tempfile
+        root = os.path.normpath(os.path.join(_PKG, ".."))
+        with tempfile.TemporaryDirectory() as td:
+            tar = os.path.join(td, "src.tar")
+            subprocess.check_call(["git", "-C", root, "archive", "-o", tar, commit, "kuiperllama_amd/csrc", "include"])
+            with tarfile.open(tar) as tf:
+                tf.extractall(td)
+            global CSRC
+            saved, CSRC = CSRC, os.path.join(td, "kuiperllama_amd", "csrc")
+            try:
+                return build_variant(name, defines)
+            finally:
+                CSRC = saved
     objs, procs = [], []
     od = os.path.join(LIB_DIR, "_" + name)
     os.makedirs(od, exist_ok=True)
@@ -92,6 +109,8 @@ def build_variant(name: str, defines: list[str]) -> str:
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # python -m kuiperllama_amd.build --variant exp_ts128 KH_ATTN_MIN_TS=128
         print(build_variant(sys.argv[2], sys.argv[3:]))
+    elif len(sys.argv) > 3 and sys.argv[1] == "--variant-at":  # ... --variant-at <commit> exp_old [defines]
+        print(build_variant(sys.argv[3], sys.argv[4:], commit=sys.argv[2]))
     else:
         print(build_lib(force="--force" in sys.argv, verbose=True))
 

@@ -20,6 +20,25 @@
 
 #define KH_ATTN_TC 2048  // timesteps per LDS score chunk (8 KiB)
 
+// Phase stamps of the decode launch (tools/mb_attn_phases.hip builds this header with -DKH_ATTN_TRACE and reads the
+// buffer back: where a launch's microseconds go, per workgroup).  Compiled out of the product.
+#ifdef KH_ATTN_TRACE
+__device__ unsigned long long* kh_attn_trace_buf;  // [gridDim.x][32] of the 100-MHz constant clock
+#define KH_ATTN_STAMP(i)                                                                     \
+  do {                                                                                       \
+    if (threadIdx.x == 0) kh_attn_trace_buf[(size_t)blockIdx.x * 32 + (i)] = wall_clock64(); \
+  } while (0)
+// per wave (slots 8 + 8 * i + wave, i = 0: first batch consumed, 1: last batch consumed)
+#define KH_ATTN_STAMP_W(i)                                                                                         \
+  do {                                                                                                             \
+    if ((threadIdx.x & 63) == 0)                                                                                   \
+      kh_attn_trace_buf[(size_t)blockIdx.x * 32 + 8 + 8 * (i) + (threadIdx.x >> 6)] = wall_clock64();              \
+  } while (0)
+#else
+#define KH_ATTN_STAMP(i) do { } while (0)
+#define KH_ATTN_STAMP_W(i) do { } while (0)
+#endif
+
 static inline size_t attn_lds_bytes(int head_size, int wg = KH_WG) {
   return (size_t)(KH_ATTN_TC + 8 + (wg / KH_WAVE) * head_size) * sizeof(float);
 }
@@ -190,6 +209,9 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 // size 128 (Llama-2-7B: -3.6 % per token at position 383, -3.9 % at 511, -2 % at 1023, -0.6 % at 2047;
 // profiles/r5_attn_7b_ts.txt).  Hook KH_ATTN_TS = 64 | 128 | 256 overrides.
 #define KH_ATTN_TS_SHIFT_MAX 8
+#ifndef KH_ATTN_TSG_SHIFT
+#define KH_ATTN_TSG_SHIFT 8  // GQA group path: log2 of its split quantum
+#endif
 #define KH_ATTN_TLONG_DEFAULT 4096  // pos + 1 from which GQA models switch to the group path
 #ifndef KH_ATTN_MAX_NS_G
 // splits per KV group (the last arriver merges them all).  16 / 24 / 48 / 64 measured: 48 / 64 (two workgroups per CU) far worse
@@ -346,6 +368,9 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
     load_batch(kv, vv, t_begin + tg);
     __builtin_amdgcn_sched_barrier(0);  // every load has left before the first instruction that waits for one
     use_batch(kv, vv, t_begin + tg);
+    KH_ATTN_STAMP(2);
+    KH_ATTN_STAMP(3);
+    KH_ATTN_STAMP_W(1);
   } else {
     // [r4] several batches: TWO register sets, the loads of batch i+2 leave when batch i has been consumed, so
     // two batches are in flight while one is computed (the plain loop issued, waited, computed: a 256-timestep
@@ -364,6 +389,7 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
     // vmcnt(0..1) on freshly issued loads (seen in the ISA).
     for (; base - tg + 2 * step < t_end; base += 2 * step) {  // a third batch exists
       use_batch(ka, va, base);
+      if (base - tg == t_begin) { KH_ATTN_STAMP(2); KH_ATTN_STAMP_W(0); }
       __builtin_amdgcn_sched_barrier(0);
       load_batch(ka, va, base + 2 * step);
       __builtin_amdgcn_sched_barrier(0);
@@ -377,8 +403,11 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
     // straight-line tails for "two left" / "three left" so that nothing is requested in vain - 40 % more code in a
     // kernel whose cost is latency, slower than this at every position but the odd-count ones.)
     use_batch(ka, va, base);
+    if (base - tg == t_begin) { KH_ATTN_STAMP(2); KH_ATTN_STAMP_W(0); }
     __builtin_amdgcn_sched_barrier(0);
     if (base - tg + step < t_end) use_batch(kb, vb, base + step);
+    KH_ATTN_STAMP(3);
+    KH_ATTN_STAMP_W(1);
   }
   // ---- merge the TPI groups: common max, rescale, sum ------------------------------------
   float mw = across_groups_max<G>(m);
@@ -411,46 +440,84 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   return M;
 }
 
-// Merge of the nact split partials of head h, element e (last arriver only).  The partials were
-// written by other workgroups: agent-scope relaxed atomic loads (vector path to L2, never a
-// stale L1 / scalar-cache line).  Loads are issued in batches of KH_ATTN_MB before any is
-// used, so the merge costs nact/KH_ATTN_MB memory round trips instead of nact.
+// Merge of the split partials in the LAST ARRIVER (all of its threads call this; uniform).  The partials were
+// written by other workgroups: agent-scope relaxed atomic loads (vector path to L2, never a stale L1 / scalar-cache
+// line).  NH heads per workgroup (1, or the KV group's kv_mul), first head h0; thread (j, e) - `mine` - returns
+// element e of head h0 + j.
+// [r5] (profiles/r5_attn_phases.txt: the merge of 32 splits took 2.9 us of a 12-us launch, of 16 splits 1.8)
+//  * ONE memory round trip: every load of the merge is requested before the first is used.  Rounds 3-4 ran two loops
+//    - the common maximum, then the weighted sums - of 16 splits per batch; agent-scope loads are not reordered by
+//    the compiler, so 32 splits paid four dependent trips;
+//  * the coefficient exp(M_k - max M) of split k is computed ONCE per (head, split) - thread j * MAXS + k loads
+//    (M, L), the maximum and the coefficients go through LDS - instead of by each of the head's hs threads for each
+//    of the nact splits (32 expf in sequence per thread were half of those 2.9 us).
+// Same terms in the same order as before and as kh_fused.h::CombStager (the deferred merge): max over the splits,
+// expf(M_k - max), one fma per split into num and den, ascending k.
+// lds: 3 * NH * MAXS floats, not overlapping the ticket word.  Requires NH * MAXS <= workgroup width.
 #define KH_ATTN_MB 16
-__device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h, int e, int hs,
-                                                   int nact, int NSW) {
-  const size_t base = (size_t)h * NSW;
-  float Mx = -INFINITY;
-  for (int k0 = 0; k0 < nact; k0 += KH_ATTN_MB) {
-    float mv[KH_ATTN_MB];
+__device__ __forceinline__ float2 ld_agent_f2(const float* p) {  // p 8-byte aligned
+  const unsigned long long w =
+      __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float2 r;
+  r.x = __uint_as_float((unsigned)(w & 0xffffffffull));
+  r.y = __uint_as_float((unsigned)(w >> 32));
+  return r;
+}
+static inline size_t attn_merge_lds_floats(int nh, int maxs) { return 16 + (size_t)3 * nh * maxs; }
+template <int NH, int MAXS, int MB>
+__device__ __forceinline__ float attn_merge_lds(const AttnSplitWs& ws, int h0, int j, int e, bool mine, int hs,
+                                                int nact, int NSW, float* lds) {
+  static_assert((MAXS & (MAXS - 1)) == 0 && MB <= MAXS, "split slots per head in LDS: a power of two");
+  float* Ms = lds;
+  float* Ls = lds + NH * MAXS;
+  float* Cf = Ls + NH * MAXS;
+  const int tid = threadIdx.x;
+  float ov[MB];
+  if (mine) {
+    const size_t base = (size_t)(h0 + j) * NSW;
 #pragma unroll
-    for (int u = 0; u < KH_ATTN_MB; ++u) {
-      const int k = k0 + u < nact ? k0 + u : nact - 1;
-      mv[u] = __hip_atomic_load(&ws.ml[(base + k) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int u = 0; u < KH_ATTN_MB; ++u) Mx = fmaxf(Mx, mv[u]);
+    for (int u = 0; u < MB; ++u)  // clamped: a re-read of the last split, dropped below
+      ov[u] = __hip_atomic_load(&ws.o[(base + (u < nact ? u : nact - 1)) * hs + e], __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (tid < NH * MAXS) {
+    const int jj = tid / MAXS, kk = tid % MAXS;
+    float2 ml;
+    ml.x = -INFINITY;
+    ml.y = 0.f;
+    if (kk < nact) ml = ld_agent_f2(&ws.ml[((size_t)(h0 + jj) * NSW + kk) * 2]);
+    Ms[tid] = ml.x;
+    Ls[tid] = ml.y;
+  }
+  __syncthreads();
+  if (tid < NH * MAXS) {
+    const int jj = tid / MAXS;
+    float Mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) Mx = fmaxf(Mx, Ms[jj * MAXS + k]);
+    Cf[tid] = expf(Ms[tid] - Mx);  // slots past nact: exp(-inf) = 0, never read
+  }
+  __syncthreads();
   float num = 0.f, den = 0.f;
-  for (int k0 = 0; k0 < nact; k0 += KH_ATTN_MB) {
-    float mv[KH_ATTN_MB], lv[KH_ATTN_MB], ov[KH_ATTN_MB];
+  if (mine) {
 #pragma unroll
-    for (int u = 0; u < KH_ATTN_MB; ++u) {
-      const int k = k0 + u < nact ? k0 + u : nact - 1;
-      const size_t sl = base + k;
-      mv[u] = __hip_atomic_load(&ws.ml[sl * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      lv[u] = __hip_atomic_load(&ws.ml[sl * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ov[u] = __hip_atomic_load(&ws.o[sl * hs + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int u = 0; u < KH_ATTN_MB; ++u) {
-      if (k0 + u < nact) {  // ascending k, one term per split: the order does not depend on MB
-        const float f = expf(mv[u] - Mx);
+    for (int u = 0; u < MB; ++u) {
+      if (u < nact) {  // ascending k, one term per split
+        const float f = Cf[j * MAXS + u];
         num = __builtin_fmaf(ov[u], f, num);
-        den = __builtin_fmaf(lv[u], f, den);
+        den = __builtin_fmaf(Ls[j * MAXS + u], f, den);
       }
     }
   }
   return num / den;
+}
+template <int NH, int MAXS>
+__device__ __forceinline__ float attn_merge_splits(const AttnSplitWs& ws, int h0, int j, int e, bool mine, int hs,
+                                                   int nact, int NSW, float* lds) {
+  static_assert(MAXS == KH_ATTN_MB || MAXS == 2 * KH_ATTN_MB, "merge batch sizes");
+  if (MAXS == KH_ATTN_MB || nact <= KH_ATTN_MB)  // uniform
+    return attn_merge_lds<NH, MAXS, KH_ATTN_MB>(ws, h0, j, e, mine, hs, nact, NSW, lds);
+  return attn_merge_lds<NH, MAXS, MAXS>(ws, h0, j, e, mine, hs, nact, NSW, lds);  // the group path's 17 ... 32
 }
 
 // agent-scope relaxed store = global_store ... sc1 (write-through): visible to every XCD once the
@@ -506,10 +573,12 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
   int TS, nact;
   attn_split_geometry(pos, NS, ts_shift, TS, nact);  // uniform over the grid; shifts only at the positions that matter
   if (s >= nact) return false;
+  KH_ATTN_STAMP(1);
   const int t_begin = s * TS;
   const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
   float r, L;
   const float M = attn_fast_partial<G>(q_h, k_base, v_base, kv_stride, hs, t_begin, t_end, smem, r, L);
+  KH_ATTN_STAMP(4);
   const size_t slot = (size_t)h * NSW + s;
   if (defer) {  // plain stores (also with ONE active split); the next kernel on the stream reads them
     if (tid < hs) ws.o[slot * hs + tid] = r;
@@ -517,10 +586,12 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
       ws.ml[slot * 2] = M;
       ws.ml[slot * 2 + 1] = L;
     }
+    KH_ATTN_STAMP(5);
     return false;
   }
   if (nact == 1) {
     if (tid < hs) out_h[tid] = r / L;
+    KH_ATTN_STAMP(5);
     return true;
   }
   // ---- publish this split's partial (write-through), take a ticket ------------------------------
@@ -530,17 +601,21 @@ __device__ __forceinline__ bool attn_head_decode_fast(const float* q_h, const fl
     st_agent(&ws.ml[slot * 2 + 1], L);
   }
   attn_publish_barrier(fenced);
+  KH_ATTN_STAMP(5);
   int* flag = (int*)smem;  // red[] is free again after the barriers inside attn_fast_partial
   if (tid == 0)
     flag[0] = __hip_atomic_fetch_add(&ws.cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  KH_ATTN_STAMP(6);
   if (flag[0] != nact - 1) return false;  // not the last arriver
   attn_acquire(fenced);
   // ---- last arriver: merge every split's partial (agent-scope loads inside) ------------------------
-  if (tid < hs) {
-    out_h[tid] = attn_merge_splits(ws, h, tid, hs, nact, NSW);
+  {
+    const float v = attn_merge_splits<1, KH_ATTN_MAX_NS>(ws, h, 0, tid < hs ? tid : 0, tid < hs, hs, nact, NSW, smem + 16);
+    if (tid < hs) out_h[tid] = v;
   }
   if (tid == 0) __hip_atomic_store(&ws.cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  KH_ATTN_STAMP(7);
   return true;
 }
 
@@ -560,7 +635,7 @@ static inline size_t attn_group_lds_bytes(int head_size, int kvm) {
 }
 // splits per KV group carried by the grid: enough workgroups to cover every CU twice
 static inline int attn_group_splits(int cache_len, int kv_heads) {
-  int ns = (cache_len + KH_ATTN_MIN_TS - 1) / KH_ATTN_MIN_TS;
+  int ns = (cache_len + (1 << KH_ATTN_TSG_SHIFT) - 1) >> KH_ATTN_TSG_SHIFT;
   int want = (512 + kv_heads - 1) / kv_heads;
   if (want > KH_ATTN_MAX_NS_G) want = KH_ATTN_MAX_NS_G;
   if (ns > want) ns = want;
@@ -648,6 +723,7 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
     int base = t_begin + tg;
     for (; base - tg + 2 * step < t_end; base += 2 * step) {  // while a third batch exists (uniform)
       if (base < t_end) use_batch(ka, va, base);
+      if (base - tg == t_begin) { KH_ATTN_STAMP(2); KH_ATTN_STAMP_W(0); }
       __builtin_amdgcn_sched_barrier(0);
       load_batch(ka, va, base + 2 * step);
       __builtin_amdgcn_sched_barrier(0);
@@ -657,8 +733,11 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
       __builtin_amdgcn_sched_barrier(0);
     }
     if (base < t_end) use_batch(ka, va, base);  // the last two batches: nothing left to request
+    if (base - tg == t_begin) { KH_ATTN_STAMP(2); KH_ATTN_STAMP_W(0); }
     __builtin_amdgcn_sched_barrier(0);
     if (base + step < t_end) use_batch(kb, vb, base + step);
+    KH_ATTN_STAMP(3);
+    KH_ATTN_STAMP_W(1);
   }
   // ---- merge the lane groups of a wave, then the waves -----------------------------------------
 #pragma unroll
@@ -697,6 +776,7 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
   r_out = r;
   L_out = L;
   M_out = M2 * 0.6931471805599453f;  // back to the natural-log domain of the split merge
+  KH_ATTN_STAMP(4);
 }
 
 // One workgroup = (kv group g, split s); heads g*KVM .. g*KVM+KVM-1.  Workspace slots and the
@@ -709,9 +789,10 @@ __device__ __forceinline__ void attn_group_decode(const float* q_g, const float*
                                                   int NS, int NSW, AttnSplitWs ws, bool fenced) {
   const int tid = threadIdx.x;
   const int nT = pos + 1;
-  const int TS = attn_split_len(nT, NS);
-  const int nact = (nT + TS - 1) / TS;  // uniform over the grid
+  int TS, nact;
+  attn_split_geometry(pos, NS, KH_ATTN_TSG_SHIFT, TS, nact);  // uniform over the grid
   if (s >= nact) return;
+  KH_ATTN_STAMP(1);
   const int t_begin = s * TS;
   const int t_end = t_begin + TS < nT ? t_begin + TS : nT;
   float r, L, M;
@@ -732,16 +813,22 @@ __device__ __forceinline__ void attn_group_decode(const float* q_g, const float*
     }
   }
   attn_publish_barrier(fenced);
+  KH_ATTN_STAMP(5);
   int* flag = (int*)smem;
   if (tid == 0)
     flag[0] = __hip_atomic_fetch_add(&ws.cnt[g * KVM], 1, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  KH_ATTN_STAMP(6);
   if (flag[0] != nact - 1) return;  // not the last arriver
   attn_acquire(fenced);
-  if (mine) out_g[(size_t)j * hs + e] = attn_merge_splits(ws, h, e, hs, nact, NSW);
+  {
+    const float v = attn_merge_splits<KVM, KH_ATTN_MAX_NS_G>(ws, g * KVM, j, mine ? e : 0, mine, hs, nact, NSW, smem + 16);
+    if (mine) out_g[(size_t)j * hs + e] = v;
+  }
   if (tid == 0)
     __hip_atomic_store(&ws.cnt[g * KVM], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  KH_ATTN_STAMP(7);
 }
 
 // =============================================================================================
@@ -807,6 +894,7 @@ __device__ __forceinline__ void attn_head_block(const KhAttnArgs& a, float* smem
 template <int G, int KVM>
 __global__ __launch_bounds__(KH_WG_MAX) void k_attn_decode(KhAttnArgs a, int host_pos) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  KH_ATTN_STAMP(0);
   int pos = a.d_pos ? *a.d_pos : host_pos;
   if (gridDim.y > 1) {  // uniform: one grid slice per prompt token
     const int t = (int)blockIdx.y;
@@ -920,7 +1008,7 @@ static inline void launch_attn_decode(KhAttnArgs a, int host_pos, int wg, hipStr
     group_splits = 0;
     for (int p = host_pos; p <= pos_hi; ++p) {
       if (grp && p + 1 >= a.t_long) {
-        const int n = attn_active_splits(p, a.nsplit_g);
+        const int n = attn_active_splits(p, a.nsplit_g, KH_ATTN_TSG_SHIFT);
         if (n > group_splits) group_splits = n;
       } else {
         const int n = attn_active_splits(p, a.nsplit, a.ts_shift);

@@ -567,7 +567,7 @@ extern "C" int kh_plan_attention(int32_t head_num, int32_t kv_mul, int32_t head_
   const bool grp = ns_g > 0 && pos + 1 >= tl;
   const int NS = grp ? ns_g : ns;
   int nact, TS;
-  attn_split_geometry(pos, NS, grp ? KH_ATTN_TS_SHIFT_MAX : attn_ts_shift_for(head_size), TS, nact);
+  attn_split_geometry(pos, NS, grp ? KH_ATTN_TSG_SHIFT : attn_ts_shift_for(head_size), TS, nact);
   out8[0] = ns;
   out8[1] = ns_g;
   out8[2] = stride;

@@ -24,8 +24,10 @@ for name in names:
     img = binfmt.synth_image(spec, seed=1234, device=dev)
     torch.cuda.synchronize()
     poss = [p for p in POS if p < spec.seq_len]
-    for label, flags in (("deferred", 0), ("in-launch", _ffi.KH_FLAG_ATTN_MERGE_IN_LAUNCH), ("deferred", 0),
-                         ("in-launch", _ffi.KH_FLAG_ATTN_MERGE_IN_LAUNCH)):
+    modes = (("deferred", 0), ("in-launch", _ffi.KH_FLAG_ATTN_MERGE_IN_LAUNCH)) * 2
+    if os.environ.get("AB_MODES"):  # e.g. AB_MODES=deferred : one pass of one mode
+        modes = tuple(m for m in modes[:2] if m[0] in os.environ["AB_MODES"].split(","))
+    for label, flags in modes:
         m = KuiperModel.from_device_image(img, spec, flags=flags)
         gen = torch.Generator(device=dev)
         gen.manual_seed(7)
