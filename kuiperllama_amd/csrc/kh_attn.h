@@ -930,6 +930,7 @@ static inline int attn_lanes(int head_size) {
 static inline bool attn_group_supported(int head_size, int kv_mul, int wg) {
   const int G = attn_lanes(head_size);
   if (kv_mul * head_size > wg) return false;
+  if (kv_mul * KH_ATTN_MAX_NS_G > wg) return false;  // attn_merge_lds: one thread per (head, split slot)
   if (G == 16) return kv_mul == 2 || kv_mul == 4 || kv_mul == 7 || kv_mul == 8;
   if (G == 32) return kv_mul == 2 || kv_mul == 4;
   return false;
