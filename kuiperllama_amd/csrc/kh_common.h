@@ -107,6 +107,44 @@ __device__ __forceinline__ float xor32_max(float v) {
   return fmaxf(a, b);
 }
 
+// Phase stamps of the decode-step GEMV kernels (tools/mb_q8ring.hip builds with -DKH_TRACE and reads them back:
+// where a launch's microseconds go, per workgroup and per wave).  Compiled out of the product.  The stamps go to LDS
+// and are flushed at the kernel's end: a global store per stamp would join the in-order vmcnt queue the register
+// tiles and the LDS-DMA ring count their loads on.
+//   0 entry | 1 input vector staged | 2 first work item finished | 3 last work item finished | 4 kernel end
+//   8 + w: wave w's last work item finished
+#ifdef KH_TRACE
+__device__ unsigned long long* kh_trace_buf;  // [gridDim.x][32] of the 100-MHz constant clock
+__device__ __forceinline__ unsigned long long* kh_trace_lds() {
+  __shared__ unsigned long long t[32];
+  return t;
+}
+#define KH_STAMP_INIT()                                      \
+  do {                                                       \
+    if (threadIdx.x < 32) kh_trace_lds()[threadIdx.x] = 0;   \
+    if (threadIdx.x == 0) kh_trace_lds()[0] = wall_clock64(); \
+  } while (0)
+#define KH_STAMP(i)                                              \
+  do {                                                           \
+    if (threadIdx.x == 0) kh_trace_lds()[(i)] = wall_clock64();  \
+  } while (0)
+#define KH_STAMP_W()                                                                                  \
+  do {                                                                                                \
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 512) kh_trace_lds()[8 + (threadIdx.x >> 6)] = wall_clock64(); \
+  } while (0)
+#define KH_STAMP_FLUSH()                                                                                   \
+  do {                                                                                                     \
+    KH_STAMP(4);                                                                                           \
+    __syncthreads();                                                                                       \
+    if (threadIdx.x < 32) kh_trace_buf[(size_t)blockIdx.x * 32 + threadIdx.x] = kh_trace_lds()[threadIdx.x]; \
+  } while (0)
+#else
+#define KH_STAMP_INIT() do { } while (0)
+#define KH_STAMP(i) do { } while (0)
+#define KH_STAMP_W() do { } while (0)
+#define KH_STAMP_FLUSH() do { } while (0)
+#endif
+
 // sum over aligned groups of G lanes (G = 1,2,4,...,64); every lane gets its group's sum
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {

@@ -67,6 +67,7 @@ struct KhQkvArgs {
 template <bool QUANT, int U, int MAXV, int SPLIT>
 __global__ __launch_bounds__(KH_WG_MAX, 4) void k_qkv(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  KH_STAMP_INIT();
   // Every kernel argument used inside the lambdas is first copied into a scalar local: a
   // lambda that captures the argument STRUCT by reference keeps the whole struct addressable
   // and the compiler then parks it in scratch memory (seen as 168 B/lane of scratch traffic).
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_qkv(const KhQkvArgs a) {
   gemv_pairs<SPLIT, /*ROLL=*/QUANT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre,
                               [&]() __attribute__((always_inline)) { st.issue(); },
                               [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi);
+  KH_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,9 +213,11 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, St& st, f3
 template <bool QUANT, int U, int MAXV, int SPLIT>
 __global__ __launch_bounds__(KH_WG_MAX, 4) void k_gemv_res(const KhGemvResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  KH_STAMP_INIT();
   f32x4* xs = (f32x4*)smem_raw;
   Stager<false, QUANT, MAXV> st(a.vec, nullptr, a.M);
   gemv_res_body<QUANT, U, SPLIT>(a, st, xs, lds_red_ptr<QUANT>(xs, a.M));
+  KH_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -393,6 +397,7 @@ struct KhFfn13Args {
 template <bool QUANT, int U, int MAXV>
 __global__ __launch_bounds__(KH_WG_MAX, 4) void k_ffn13(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  KH_STAMP_INIT();
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
   const int lane = threadIdx.x & 63;
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_ffn13(const KhFfn13Args a) {
   gemv_pairs<1, /*ROLL=*/false>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
                        [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
+  KH_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -421,6 +427,7 @@ struct KhClsArgs {
 template <bool QUANT, int U, int MAXV>
 __global__ __launch_bounds__(KH_WG_MAX, 4) void k_cls(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  KH_STAMP_INIT();
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<QUANT>(xs, a.dim);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_cls(const KhClsArgs a) {
     a.part_val[blockIdx.x] = v;
     a.part_idx[blockIdx.x] = i;
   }
+  KH_STAMP_FLUSH();
 }
 static inline size_t cls_lds_bytes(bool quant, int M) {
   return fused_lds_bytes(quant, M) + KH_WAVES_MAX * sizeof(int);

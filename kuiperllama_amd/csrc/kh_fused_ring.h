@@ -17,6 +17,7 @@ using RingStager = typename std::conditional<STG == 1, StagerAsm<NORM, MAXV, VT>
 template <int R, int MAXV, bool BLOCKED = false, int VT = 0, int STG = 0>
 __global__ __launch_bounds__(1024) void k_ffn13_ring(const KhFfn13Args a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
+  KH_STAMP_INIT();
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<true>(xs, a.dim);
   const int lane = threadIdx.x & 63;
@@ -36,11 +37,13 @@ __global__ __launch_bounds__(1024) void k_ffn13_ring(const KhFfn13Args a) {
       [](int) __attribute__((always_inline)) { return NoAux{}; },
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
+  KH_STAMP_FLUSH();
 }
 
 template <int R, int MAXV, bool BLOCKED = false, int VT = 0, int STG = 0>
 __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
+  KH_STAMP_INIT();
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<true>(xs, a.dim);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -85,12 +88,14 @@ __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
     a.part_val[blockIdx.x] = v;
     a.part_idx[blockIdx.x] = i;
   }
+  KH_STAMP_FLUSH();
 }
 
 // y = W . v ; x += y (wo, w2).  The residual words x[2p], x[2p+1] come through the scalar cache (ld_uniform).
 template <int R, int MAXV, int SPLIT, int STG = 0>
 __global__ __launch_bounds__(1024) void k_gemv_res_ring(const KhGemvResArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
+  KH_STAMP_INIT();
   f32x4* xs = (f32x4*)smem_raw;
   float* red = lds_red_ptr<true>(xs, a.M);
   const int lane = threadIdx.x & 63;
@@ -114,6 +119,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_ring(const KhGemvResArgs a) {
       M, a.gshift, xs, a.K >> 1, lane, red + KH_WAVES_MAX, smem_raw + ring_lds_off(M, false), pair, auxf,
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(0.f, red, exact); }, epi);
+  KH_STAMP_FLUSH();
 }
 
 // RMSNorm(x) -> [wq|wk|wv] row pairs -> +bias -> RoPE -> q / cache row `pos` (k_qkv<true, ...>).  The epilogue
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(1024) void k_gemv_res_ring(const KhGemvResArgs a) {
 template <int R, int MAXV, int SPLIT, int STG = 0>
 __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
+  KH_STAMP_INIT();
   const void *wq_w = a.wq.w, *wk_w = a.wk.w, *wv_w = a.wv.w;
   const float *wq_s = a.wq.scales, *wk_s = a.wk.scales, *wv_s = a.wv.scales;
   const float *wq_b = a.wq.bias, *wk_b = a.wk.bias, *wv_b = a.wv.bias;
@@ -206,4 +213,5 @@ __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
       dim, a.gshift, xs, total, lane, red + KH_WAVES_MAX, smem_raw + ring_lds_off(dim, STG == 0), pair, auxf,
       [&]() __attribute__((always_inline)) { st.issue(); },
       [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
+  KH_STAMP_FLUSH();
 }

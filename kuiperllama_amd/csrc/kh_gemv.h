@@ -273,6 +273,7 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
   g.load(regs, cur, cb, ce, lane);
   auto aux = PRE(p0);
   FINISH();
+  KH_STAMP(1);
   const int iters = (total + np - 1) / np;  // uniform trip count: the SPLIT path has barriers
   // The tile registers ROLL: slot u of the next tile is requested right after slot u of the current
   // tile was consumed, so (U-1)/U of a tile stays in flight while the wave computes - with "consume
@@ -347,6 +348,8 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
     }
     if (last) {
       finish_item(p, valid, a0, a1, aux);
+      if (it == 0) KH_STAMP(2);
+      if (!more) KH_STAMP_W();  // the wave's last item (waves without one stamp their first pass)
       aux = aux_next;
       a0 = a1 = 0.f;
       if (++it == iters) break;
@@ -354,6 +357,7 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
     p = pn;
     c0 = cn;
   }
+  KH_STAMP(3);
 }
 struct NoAux {};
 

@@ -313,6 +313,7 @@ __device__ __forceinline__ void ring_pairs(int M, int gshift, const f32x4* xs, i
   const int n0 = N < R ? N : R;
   for (int k = 0; k < n0; ++k) issue1();
   FINISH(n0 == R);
+  KH_STAMP(1);
 
   // ---- the consume side
   int pc = gp, cc = cb;
@@ -373,6 +374,7 @@ __device__ __forceinline__ void ring_pairs(int M, int gshift, const f32x4* xs, i
     if (sc == (unsigned)(R * KH_RING_SLOT)) sc = 0;
     if (cc >= ce) {
       finish_item();
+      if (pc == gp) KH_STAMP(2);
       pc += np;
       cc = cb;
       a0 = a1 = 0.f;
@@ -384,6 +386,8 @@ __device__ __forceinline__ void ring_pairs(int M, int gshift, const f32x4* xs, i
   ring_tail<R - 1>(k, N, [&](auto jt) __attribute__((always_inline)) {
     consume(std::integral_constant<int, OPS * decltype(jt)::value>{}, std::false_type{});
   });
+  KH_STAMP_W();
+  KH_STAMP(3);
   if constexpr (SPLIT > 1) {
     const int span = BLOCKED ? total - vb * ipw : total;  // items the workgroup's waves share
     const int iters = span > 0 ? (span + np - 1) / np : 0;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <algorithm>
 #include <vector>
 
 #include "kh_fused_ring.h"
@@ -46,6 +47,55 @@ static float time_graph(int NL0, const std::function<void(int)>& launch) {
   CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
   return best * 1e3f / NL;
 }
+
+// -DKH_TRACE: phase stamps of one launch per slab (kh_common.h::KH_STAMP): 0 entry, 1 vector staged, 2 first work item
+// finished, 3 thread 0's wave done, 4 kernel end; 8 + w: wave w done.  Launches are NOT back to back here: every traced
+// launch starts on an idle chip with cold weights.
+#ifdef KH_TRACE
+static unsigned long long* g_tr = nullptr;
+static void trace_report(const char* name, const char* variant, int grid, int nslab, const std::function<void(int)>& launch) {
+  double late[5] = {0}, med[5] = {0}, spread = 0, lastwave = 0, firstdone = 0;
+  std::vector<unsigned long long> h((size_t)grid * 32);
+  for (int l = 0; l < nslab; ++l) {
+    CK(hipMemsetAsync(g_tr, 0, (size_t)grid * 256, S));
+    launch(l);
+    CK(hipStreamSynchronize(S));
+    CK(hipMemcpy(h.data(), g_tr, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < grid; ++b) if (h[(size_t)b * 32]) t0 = std::min(t0, h[(size_t)b * 32]);
+    std::vector<double> ph[5], sp;
+    double lt[5] = {0}, lw = 0, fd = 1e30;
+    for (int b = 0; b < grid; ++b) {
+      const unsigned long long* s = &h[(size_t)b * 32];
+      if (!s[0]) continue;
+      unsigned long long prev = s[0];
+      for (int i = 0; i < 5; ++i) {
+        if (!s[i]) continue;
+        lt[i] = std::max(lt[i], (double)(s[i] - t0) * 0.01);
+        if (i) ph[i].push_back((double)(s[i] - prev) * 0.01);
+        prev = s[i];
+      }
+      unsigned long long lo = ~0ull, hi = 0;
+      for (int w = 0; w < 8; ++w) if (s[8 + w]) { lo = std::min(lo, s[8 + w]); hi = std::max(hi, s[8 + w]); }
+      if (hi) { sp.push_back((double)(hi - lo) * 0.01); lw = std::max(lw, (double)(hi - t0) * 0.01); fd = std::min(fd, (double)(lo - t0) * 0.01); }
+    }
+    for (int i = 0; i < 5; ++i) {
+      late[i] += lt[i] / nslab;
+      if (!ph[i].empty()) { std::sort(ph[i].begin(), ph[i].end()); med[i] += ph[i][ph[i].size() / 2] / nslab; }
+    }
+    if (!sp.empty()) { std::sort(sp.begin(), sp.end()); spread += sp[sp.size() / 2] / nslab; }
+    lastwave += lw / nslab;
+    firstdone += fd / nslab;
+  }
+  printf("   trace %-6s %-28s latest workgroup: entry %.2f | staged %.2f | item1 %.2f | wave0 done %.2f | end %.2f   "
+         "median phases: stage %.2f | item1 %.2f | rest %.2f | tail %.2f   waves: first done %.2f, last done %.2f, spread inside a workgroup %.2f\n",
+         name, variant, late[0], late[1], late[2], late[3], late[4], med[1], med[2], med[3], med[4], firstdone, lastwave, spread);
+  fflush(stdout);
+}
+#define TRACE(name, variant, grid, ...) trace_report(name, variant, grid, 8, __VA_ARGS__)
+#else
+#define TRACE(name, variant, grid, ...) do { } while (0)
+#endif
 template <class K>
 static void optin(K k, size_t lds) {
   if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -73,6 +123,10 @@ int main(int argc, char** argv) {
   const int shift = argc > 2 ? atoi(argv[2]) : 0;  // bytes the weight / scale arrays sit off a 4-KiB boundary (a device image
                                                    // that still carries its 32-byte header puts every row 32 B off a line)
   CK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
+#ifdef KH_TRACE  // every kernel of this build flushes its stamps: the buffer exists before the first launch
+  CK(hipMalloc(&g_tr, (size_t)4096 * 32 * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(kh_trace_buf), &g_tr, sizeof(g_tr)));
+#endif
   const int dim = 4096, hidden = 11008, vocab = 32000, NL = 32, gshift = 6;
   const size_t slab_max = (size_t)vocab * dim;  // cls is the largest matrix (131 MB); ffn13 = 2 * 11008 * 4096 = 90 MB
   int8_t* w; float* sc;
@@ -108,6 +162,11 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_ffn13<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     report("ffn13", "shipped wg256 grid512 U4", base, bytes, true, 0);
+    TRACE("ffn13", "shipped wg256 grid512", 512, [&](int l) { hipLaunchKernelGGL((k_ffn13<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
+    {
+      const size_t ldsr = ring_lds_bytes(dim, false, 4, 2);
+      TRACE("ffn13", "ring R2 wg256 grid512 x:regs", 512, [&](int l) { hipLaunchKernelGGL((k_ffn13_ring<2, 4, false, 0, 1>), dim3(512), dim3(256), ldsr, S, args(l, o_new)); });
+    }
 #define FFN_RINGX(RR, MV, WG, GRID, BL, VT) FFN_RINGS(RR, MV, WG, GRID, BL, VT, 0)
 #define FFN_RINGS(RR, MV, WG, GRID, BL, VT, STG)                                                                          \
   do {                                                                                                                    \
@@ -154,6 +213,11 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_cls<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     report("cls", "shipped wg256 grid512 U4", base, bytes, true, 0);
+    TRACE("cls", "shipped wg256 grid512", 512, [&](int l) { hipLaunchKernelGGL((k_cls<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
+    {
+      const size_t ldsr = ring_lds_bytes(dim, false, 4, 2);
+      TRACE("cls", "ring R2 wg256 grid512 x:regs", 512, [&](int l) { hipLaunchKernelGGL((k_cls_ring<2, 4, false, 0, 1>), dim3(512), dim3(256), ldsr, S, args(l, o_new)); });
+    }
 #define CLS_RINGS(RR, MV, WG, GRID, STG)                                                                                  \
   do {                                                                                                                    \
     const size_t lds = ring_lds_off(dim, (STG) == 0) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                         \
@@ -195,6 +259,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { ship(l, o_new); });
     report(name, which == 2 ? "shipped wg256 grid512 U4 split1" : "shipped wg512 grid512 U2 split2", base, bytes, true, 0);
+    TRACE(name, "shipped", 512, [&](int l) { ship(l, o_new); });
 #define RES_RINGS(RR, MV, SP, WG, GRID, STG)                                                                              \
   do {                                                                                                                    \
     const size_t lds = ring_lds_off(M, false) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                                \
@@ -250,6 +315,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(S));
     const float base = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_qkv<true, 4, 4, 1>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     report("qkv", "shipped wg256 grid512 U4", base, bytes, true, 0);
+    TRACE("qkv", "shipped wg256 grid512", 512, [&](int l) { hipLaunchKernelGGL((k_qkv<true, 4, 4, 1>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
 #define QKV_RINGS(RR, MV, WG, GRID, STG)                                                                                  \
   do {                                                                                                                    \
     const size_t lds = ring_lds_off(dim, (STG) == 0) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                         \
