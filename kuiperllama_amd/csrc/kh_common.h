@@ -112,6 +112,7 @@ __device__ __forceinline__ float xor32_max(float v) {
 // and are flushed at the kernel's end: a global store per stamp would join the in-order vmcnt queue the register
 // tiles and the LDS-DMA ring count their loads on.
 //   0 entry | 1 input vector staged | 2 first work item finished | 3 last work item finished | 4 kernel end
+//   5 vector and first tile requested | 6 vector arrived (sum of squares formed) | 7 block sum done
 //   8 + w: wave w's last work item finished
 #ifdef KH_TRACE
 __device__ unsigned long long* kh_trace_buf;  // [gridDim.x][32] of the 100-MHz constant clock
@@ -126,7 +127,9 @@ __device__ __forceinline__ unsigned long long* kh_trace_lds() {
   } while (0)
 #define KH_STAMP(i)                                              \
   do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
     if (threadIdx.x == 0) kh_trace_lds()[(i)] = wall_clock64();  \
+    __builtin_amdgcn_sched_barrier(0);                           \
   } while (0)
 #define KH_STAMP_W()                                                                                  \
   do {                                                                                                \

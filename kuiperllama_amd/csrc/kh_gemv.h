@@ -439,6 +439,7 @@ struct Stager {
     } else {
       const int M4 = M >> 2, M16 = M >> 4;
       float rs = 1.f;
+      KH_STAMP(5);
       if (NORM) {
         float ss = 0.f;
 #pragma unroll
@@ -446,8 +447,13 @@ struct Stager {
           const float t = fma4(xv[v], xv[v], 0.f);
           ss += (threadIdx.x + v * kh_wg() < M4) ? t : 0.f;
         }
+#ifdef KH_TRACE
+        asm volatile("" :: "v"(ss));  // the stamp below is taken once the vector has arrived
+#endif
+        KH_STAMP(6);
         ss = block_sum(ss, red);
         rs = 1.0f / sqrtf(ss / (float)M + eps);
+        KH_STAMP(7);
       }
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {

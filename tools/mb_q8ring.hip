@@ -54,7 +54,7 @@ static float time_graph(int NL0, const std::function<void(int)>& launch) {
 #ifdef KH_TRACE
 static unsigned long long* g_tr = nullptr;
 static void trace_report(const char* name, const char* variant, int grid, int nslab, const std::function<void(int)>& launch) {
-  double late[5] = {0}, med[5] = {0}, spread = 0, lastwave = 0, firstdone = 0;
+  double late[5] = {0}, med[5] = {0}, spread = 0, lastwave = 0, firstdone = 0, sub[3] = {0};
   std::vector<unsigned long long> h((size_t)grid * 32);
   for (int l = 0; l < nslab; ++l) {
     CK(hipMemsetAsync(g_tr, 0, (size_t)grid * 256, S));
@@ -63,7 +63,7 @@ static void trace_report(const char* name, const char* variant, int grid, int ns
     CK(hipMemcpy(h.data(), g_tr, h.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < grid; ++b) if (h[(size_t)b * 32]) t0 = std::min(t0, h[(size_t)b * 32]);
-    std::vector<double> ph[5], sp;
+    std::vector<double> ph[5], sp, sb[3];
     double lt[5] = {0}, lw = 0, fd = 1e30;
     for (int b = 0; b < grid; ++b) {
       const unsigned long long* s = &h[(size_t)b * 32];
@@ -75,6 +75,9 @@ static void trace_report(const char* name, const char* variant, int grid, int ns
         if (i) ph[i].push_back((double)(s[i] - prev) * 0.01);
         prev = s[i];
       }
+      if (s[5]) sb[0].push_back((double)(s[5] - s[0]) * 0.01);          // entry -> everything requested
+      if (s[5] && s[6]) sb[1].push_back((double)(s[6] - s[5]) * 0.01);  // -> vector arrived
+      if (s[6] && s[7]) sb[2].push_back((double)(s[7] - s[6]) * 0.01);  // -> block sum done
       unsigned long long lo = ~0ull, hi = 0;
       for (int w = 0; w < 8; ++w) if (s[8 + w]) { lo = std::min(lo, s[8 + w]); hi = std::max(hi, s[8 + w]); }
       if (hi) { sp.push_back((double)(hi - lo) * 0.01); lw = std::max(lw, (double)(hi - t0) * 0.01); fd = std::min(fd, (double)(lo - t0) * 0.01); }
@@ -84,12 +87,17 @@ static void trace_report(const char* name, const char* variant, int grid, int ns
       if (!ph[i].empty()) { std::sort(ph[i].begin(), ph[i].end()); med[i] += ph[i][ph[i].size() / 2] / nslab; }
     }
     if (!sp.empty()) { std::sort(sp.begin(), sp.end()); spread += sp[sp.size() / 2] / nslab; }
+    for (int i = 0; i < 3; ++i)
+      if (!sb[i].empty()) { std::sort(sb[i].begin(), sb[i].end()); sub[i] += sb[i][sb[i].size() / 2] / nslab; }
     lastwave += lw / nslab;
     firstdone += fd / nslab;
   }
   printf("   trace %-6s %-28s latest workgroup: entry %.2f | staged %.2f | item1 %.2f | wave0 done %.2f | end %.2f   "
          "median phases: stage %.2f | item1 %.2f | rest %.2f | tail %.2f   waves: first done %.2f, last done %.2f, spread inside a workgroup %.2f\n",
          name, variant, late[0], late[1], late[2], late[3], late[4], med[1], med[2], med[3], med[4], firstdone, lastwave, spread);
+  if (sub[0] > 0)
+    printf("         inside the stage (register-tile staging only): entry -> all requested %.2f | -> vector arrived %.2f | -> block sum %.2f\n",
+           sub[0], sub[1], sub[2]);
   fflush(stdout);
 }
 #define TRACE(name, variant, grid, ...) trace_report(name, variant, grid, 8, __VA_ARGS__)
