@@ -303,7 +303,7 @@ void launch_ffn13(kh_model* m, int l) {
   a.eps = c.rms_eps;
   const bool qn = c.is_quant;
   if (m->ring.ffn_r == 2) {  // plan_ring: int8, dim a multiple of 256 floats and at most 16 per thread
-    hipLaunchKernelGGL((k_ffn13_ring<2, 4, false, 0, 1>), dim3(m->ring.ffn_grid), dim3(KH_WG),
+    hipLaunchKernelGGL((k_ffn13_ring<2, 4>), dim3(m->ring.ffn_grid), dim3(KH_WG),
                        ring_lds_bytes(c.dim, false, KH_WAVES_PER_WG, 2), m->stream, a);
     return;
   }
@@ -341,7 +341,7 @@ void launch_cls(kh_model* m) {
   // the classifier is int8 only when the model is quantised (untied; llama3.cpp:255-268)
   const bool qn = c.is_quant;
   if (m->ring.cls_r == 2) {
-    hipLaunchKernelGGL((k_cls_ring<2, 4, false, 0, 1>), dim3(m->ring.cls_grid), dim3(KH_WG),
+    hipLaunchKernelGGL((k_cls_ring<2, 4>), dim3(m->ring.cls_grid), dim3(KH_WG),
                        ring_lds_bytes(c.dim, false, KH_WAVES_PER_WG, 2), m->stream, a);
     return;
   }

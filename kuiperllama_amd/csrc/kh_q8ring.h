@@ -21,7 +21,7 @@
 // The compiler does not know that the asm DMA operations occupy vmcnt slots; its own s_waitcnt for a
 // compiler-visible global LOAD would therefore drain the ring.  Hence: no vector load the compiler knows about
 // while the ring is live.  The activation vector is fetched by asm register loads with a hand-placed wait
-// (StagerAsm; StagerDma is the measured-equal alternative through the DMA path), epilogue operands (residual,
+// (StagerAsm; tools/ring_variants.h::StagerDma is the measured-equal alternative through the DMA path), epilogue operands (residual,
 // sin / cos, bias) through the scalar cache (ld_uniform: lgkmcnt), pointers and sizes are kernel arguments.
 // Stores are fine (nothing waits for them; vmcnt(N) with extra younger stores only over-waits).
 #pragma once
@@ -39,13 +39,6 @@ __device__ __forceinline__ unsigned kh_lds_addr(const void* p) {
 // 64 lanes x 16 B from (base + voff[lane]) to LDS [dst + 16 * lane]; dst is wave-uniform.  Weights: read once, nt.
 __device__ __forceinline__ void dma_x4(const void* base, unsigned voff, unsigned dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
-               :
-               : "v"(voff), "s"(base), "s"(dst)
-               : "memory");
-}
-// the same with the default cache policy (the activation vector: every workgroup reads it, it lives in L2)
-__device__ __forceinline__ void dma_x4_keep(const void* base, unsigned voff, unsigned dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                :
                : "v"(voff), "s"(base), "s"(dst)
                : "memory");
@@ -70,106 +63,18 @@ __device__ __forceinline__ float ld_uniform(const float* p) {
   return *(const __attribute__((address_space(4))) float*)(unsigned long long)p;
 }
 
-// Input vector staging through the DMA path - the alternative to StagerAsm, measured equal within 0.5 % on all five
-// kernels (profiles/r5_int8_ring_ab.txt section 6) and not used by the product: the waves pull the raw vector into the
-// xs area (linear) and the norm weight into its own area with 1-KiB pieces, issued BEFORE the ring prologue, finish()
-// waits for exactly the prologue's operation count, then permutes (and normalises) in place through registers: the
-// element -> thread mapping and the arithmetic are Stager<NORM, true, MAXV>'s, so the staged vector is bit-identical.
-// Costs two more barriers, an LDS round trip and M floats of LDS for the norm weight; needs M % 256 == 0 (whole
-// 1-KiB pieces).  (It was written when the first ring version seemed to stage wrong vectors through register loads;
-// that was the microbenchmark overwriting its own reference output - tools/mb_vmcnt_order.hip shows that register
-// loads and LDS-DMA operations do retire in issue order through vmcnt, and StagerAsm is bit-identical.)
-// VT: the element -> thread mapping and the norm's reduction tree are those of a VT-thread workgroup (0: the real
-// width); threads past VT only take part in the barriers.  Lets a workgroup of any width (11 waves, ...) stage
-// exactly what the 256-thread kernels stage.
-template <bool NORM, int MAXV, int VT = 0>
-struct StagerDma {
-  const float* x;
-  const float* wnorm;
-  f32x4* xs;         // q8-layout area; receives the raw vector first
-  const f32x4* wraw;  // NORM: raw norm weight area (M floats)
-  int M;
-  __device__ __forceinline__ StagerDma(const float* x_, const float* wnorm_, f32x4* xs_, const void* wraw_, int M_)
-      : x(x_), wnorm(wnorm_), xs(xs_), wraw((const f32x4*)wraw_), M(M_) {}
-  __device__ __forceinline__ void issue() {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = kh_nwaves();
-    const unsigned lane16 = (threadIdx.x & 63u) << 4;
-    const unsigned xs0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kh_lds_addr(xs));
-    const unsigned wr0 = (unsigned)__builtin_amdgcn_readfirstlane((int)kh_lds_addr(wraw));
-    const int npieces = M >> 8;
-    for (int pc = wave; pc < npieces; pc += nw) {
-      dma_x4_keep(x, (unsigned)pc * 1024u + lane16, xs0 + (unsigned)pc * 1024u);
-      if (NORM) dma_x4_keep(wnorm, (unsigned)pc * 1024u + lane16, wr0 + (unsigned)pc * 1024u);
-    }
-  }
-  template <int YOUNGER>
-  __device__ __forceinline__ void finish(float eps, float* red, bool exact) {
-    if (exact)
-      wait_vm<YOUNGER>();
-    else
-      wait_vm<0>();
-    __syncthreads();  // every wave's pieces have landed
-    const int M4 = M >> 2, M16 = M >> 4;
-    const int wgv = VT ? VT : kh_wg();
-    const bool act = (int)threadIdx.x < wgv;
-    f32x4 xv[MAXV], wv[NORM ? MAXV : 1];
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int i = threadIdx.x + v * wgv;
-      const int ci = (act && i < M4) ? i : 0;
-      xv[v] = xs[ci];
-      if (NORM) wv[v] = wraw[ci];
-    }
-    float rs = 1.f;
-    if (NORM) {
-      float ss = 0.f;
-#pragma unroll
-      for (int v = 0; v < MAXV; ++v) {
-        const float t = fma4(xv[v], xv[v], 0.f);
-        ss += (act && (int)threadIdx.x + v * wgv < M4) ? t : 0.f;
-      }
-      // block_sum over the wgv / 64 waves that staged; its barriers also separate the raw reads above from the
-      // permuted writes below
-      ss = wave_sum(ss);
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvw = wgv >> 6;
-      if (lane == 0 && wave < nvw) red[wave] = ss;
-      __syncthreads();
-      float r = 0.f;
-#pragma unroll
-      for (int w = 0; w < KH_WAVES_MAX; ++w) r += w < nvw ? red[w < nvw ? w : 0] : 0.f;
-      __syncthreads();
-      rs = 1.0f / sqrtf(r / (float)M + eps);
-    } else {
-      __syncthreads();
-    }
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int i = threadIdx.x + v * wgv;
-      if (act && i < M4) {
-        f32x4 t = xv[v];
-        if (NORM) {
-          t.x = wv[v].x * (rs * t.x);
-          t.y = wv[v].y * (rs * t.y);
-          t.z = wv[v].z * (rs * t.z);
-          t.w = wv[v].w * (rs * t.w);
-        }
-        xs[q8_slot(i, M16)] = t;
-      }
-    }
-    __syncthreads();
-  }
-};
-
 // Input vector staging with register loads issued by inline asm (the compiler must not know them: its own wait
 // for a load it knows about counts only the loads it knows about and would drain the ring behind it).  issue()
 // requests MAXV float4 of x (and of the norm weight) per thread, exactly like Stager; finish() waits for exactly
 // those - the YOUNGER operations of the ring prologue stay in flight (loads and LDS-DMA operations retire in issue
 // order through the one vmcnt counter: tools/mb_vmcnt_order.hip) - ties every loaded register to the wait so that no
 // use can be scheduled ahead of it, and then does what Stager<NORM, true, MAXV>::finish does, in the same order.
-// Against StagerDma: no LDS detour, two barriers fewer, no raw norm-weight area in LDS.
+// Against tools/ring_variants.h::StagerDma (the same through LDS-DMA pieces, measured equal): no LDS detour, two
+// barriers fewer, no raw norm-weight area in LDS.
 template <bool NORM, int MAXV, int VT = 0>
 struct StagerAsm {
   static_assert(VT == 0, "the register staging uses the real workgroup width");
+  static constexpr bool kRawArea = false;  // no raw norm-weight area between the reduction words and the rings
   f32x4 xv[MAXV];
   f32x4 wv[NORM ? MAXV : 1];
   const float* x;
@@ -238,7 +143,8 @@ __device__ __forceinline__ void ring_tail(int& k, int N, F&& f) {
   if constexpr (J > 0) ring_tail<J - 1>(k, N, f);
 }
 
-// xs (q8 layout) | red[KH_WAVES_MAX] | comb[2 * KH_WAVES_MAX] | pad to 256 | NORM: raw norm weight (M floats) | rings
+// xs (q8 layout) | red[KH_WAVES_MAX] | comb[2 * KH_WAVES_MAX] | pad to 256 | (StagerDma + norm only: raw norm weight,
+// M floats) | rings
 __host__ __device__ static inline size_t ring_lds_wraw_off(int M) {
   const size_t xs_bytes = (size_t)4 * (size_t)(M / 16 + 1) * 16;  // kh_q8_lds_bytes
   return ((xs_bytes + 3 * KH_WAVES_MAX * sizeof(float)) + 255) & ~(size_t)255;
@@ -254,8 +160,8 @@ static inline size_t ring_lds_bytes(int M, bool norm, int waves, int R) {
 //   PAIR(p)        -> RowsQ8 of work item p (scalar address arithmetic)
 //   AUX(p)         -> small struct of epilogue operands fetched through the scalar cache (ld_uniform) when the
 //                     item's first piece is consumed - no vector load may be issued while the ring is live
-//   ISSUE()        -> StagerDma::issue
-//   FINISH(exact)  -> StagerDma::finish<R * 4>(..., exact)
+//   ISSUE()        -> StagerAsm::issue
+//   FINISH(exact)  -> StagerAsm::finish<R * 4>(..., exact)
 //   EPI(p, s0, s1, aux) -> epilogue with the two dot products
 // BLOCKED: workgroup b owns the contiguous items [b * ipw, (b + 1) * ipw), ipw = ceil(total / grid), and its waves
 // take them round-robin - with one workgroup per CU every CU streams the same number of bytes whatever the wave

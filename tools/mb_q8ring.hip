@@ -2,7 +2,7 @@
 // LDS-DMA ring kernels (kh_fused_ring.h) on the Llama-2-7B int8 shapes (group 64), random weights.
 // For every kernel: (1) outputs compared BITWISE with the shipped kernel's on the same inputs, (2) us per launch of
 // a hipGraph of NL launches over NL distinct weight slabs (nothing is served from a cache), best of 5.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++20 -I kuiperllama_amd/csrc tools/mb_q8ring.hip -o kuiperllama_amd/lib/mb_q8ring
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++20 -I kuiperllama_amd/csrc -I tools tools/mb_q8ring.hip -o kuiperllama_amd/lib/mb_q8ring
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,7 +10,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "kh_fused_ring.h"
+#include "ring_variants.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 __global__ void k_fill_i8(int8_t* p, size_t n, uint32_t seed) {
@@ -173,19 +173,19 @@ int main(int argc, char** argv) {
     TRACE("ffn13", "shipped wg256 grid512", 512, [&](int l) { hipLaunchKernelGGL((k_ffn13<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     {
       const size_t ldsr = ring_lds_bytes(dim, false, 4, 2);
-      TRACE("ffn13", "ring R2 wg256 grid512 x:regs", 512, [&](int l) { hipLaunchKernelGGL((k_ffn13_ring<2, 4, false, 0, 1>), dim3(512), dim3(256), ldsr, S, args(l, o_new)); });
+      TRACE("ffn13", "ring R2 wg256 grid512 x:regs", 512, [&](int l) { hipLaunchKernelGGL((k_ffn13_ring<2, 4>), dim3(512), dim3(256), ldsr, S, args(l, o_new)); });
     }
 #define FFN_RINGX(RR, MV, WG, GRID, BL, VT) FFN_RINGS(RR, MV, WG, GRID, BL, VT, 0)
 #define FFN_RINGS(RR, MV, WG, GRID, BL, VT, STG)                                                                          \
   do {                                                                                                                    \
     const size_t lds = ring_lds_off(dim, (STG) == 0) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                         \
     if (lds * (((GRID) + 255) / 256) > 160 * 1024) { printf("ffn13  ring R%d wg%d grid%d: LDS does not fit\n", RR, WG, GRID); break; } \
-    optin(k_ffn13_ring<RR, MV, BL, VT, STG>, lds);                                                                        \
+    optin(k_ffn13_ring<RR, MV, BL, RingStager<true, MV, VT, STG>>, lds);                                                                        \
     CK(hipMemsetAsync(o_new, 0xff, hidden * 4, S));                                                                       \
-    hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, VT, STG>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                \
+    hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, RingStager<true, MV, VT, STG>>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                \
     CK(hipStreamSynchronize(S));                                                                                          \
     const bool ok = same(((WG) == 256 || (VT) == 256) ? o_ref : o_ref512, o_new, hidden, "ffn13 h");                      \
-    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, VT, STG>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
+    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_ffn13_ring<RR, MV, BL, RingStager<true, MV, VT, STG>>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
     char v[96]; snprintf(v, sizeof v, "ring R%d wg%d grid%d%s %s (%zu KB)", RR, WG, GRID, (BL) ? " blocked" : "",         \
                          (STG) ? "x:regs" : "x:dma", lds >> 10);                                                          \
     report("ffn13", v, t, bytes, ok, base);                                                                               \
@@ -224,18 +224,18 @@ int main(int argc, char** argv) {
     TRACE("cls", "shipped wg256 grid512", 512, [&](int l) { hipLaunchKernelGGL((k_cls<true, 4, 4>), dim3(512), dim3(256), lds0, S, args(l, o_new)); });
     {
       const size_t ldsr = ring_lds_bytes(dim, false, 4, 2);
-      TRACE("cls", "ring R2 wg256 grid512 x:regs", 512, [&](int l) { hipLaunchKernelGGL((k_cls_ring<2, 4, false, 0, 1>), dim3(512), dim3(256), ldsr, S, args(l, o_new)); });
+      TRACE("cls", "ring R2 wg256 grid512 x:regs", 512, [&](int l) { hipLaunchKernelGGL((k_cls_ring<2, 4>), dim3(512), dim3(256), ldsr, S, args(l, o_new)); });
     }
 #define CLS_RINGS(RR, MV, WG, GRID, STG)                                                                                  \
   do {                                                                                                                    \
     const size_t lds = ring_lds_off(dim, (STG) == 0) + (size_t)((WG) / 64) * (RR) * KH_RING_SLOT;                         \
     if (lds * (((GRID) + 255) / 256) > 160 * 1024) { printf("cls    ring R%d wg%d grid%d: LDS does not fit\n", RR, WG, GRID); break; } \
-    optin(k_cls_ring<RR, MV, false, 0, STG>, lds);                                                                        \
+    optin(k_cls_ring<RR, MV, false, RingStager<true, MV, 0, STG>>, lds);                                                                        \
     CK(hipMemsetAsync(o_new, 0xff, vocab * 4, S));                                                                        \
-    hipLaunchKernelGGL((k_cls_ring<RR, MV, false, 0, STG>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                \
+    hipLaunchKernelGGL((k_cls_ring<RR, MV, false, RingStager<true, MV, 0, STG>>), dim3(GRID), dim3(WG), lds, S, args(0, o_new));                \
     CK(hipStreamSynchronize(S));                                                                                          \
     const bool ok = same((WG) == 256 ? o_ref : o_ref512, o_new, vocab, "cls logits");                                     \
-    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_cls_ring<RR, MV, false, 0, STG>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
+    const float t = time_graph(NL, [&](int l) { hipLaunchKernelGGL((k_cls_ring<RR, MV, false, RingStager<true, MV, 0, STG>>), dim3(GRID), dim3(WG), lds, S, args(l, o_new)); }); \
     char v[96]; snprintf(v, sizeof v, "ring R%d wg%d grid%d %s (%zu KB)", RR, WG, GRID, (STG) ? "x:regs" : "x:dma", lds >> 10); \
     report("cls", v, t, bytes, ok, base);                                                                                 \
   } while (0)
