@@ -36,7 +36,10 @@ enum {
   KH_ERR_IO = -3,          /* file open/map failure (reference: error::PathNotValid) */
   KH_ERR_FORMAT = -4,      /* malformed .bin (reference: error::ModelParseError) */
   KH_ERR_NO_DEVICE = -5,
-  KH_ERR_RANGE = -6        /* token / position out of range */
+  KH_ERR_RANGE = -6,       /* token / position out of range */
+  KH_ERR_INTERNAL = -7     /* a C++ exception inside the library (host allocation, thread creation): caught at the
+                              boundary, everything the call had built is released; host out-of-memory is reported as
+                              hipErrorOutOfMemory (2) */
 };
 const char* kh_error_string(int code);
 int kh_version(void);

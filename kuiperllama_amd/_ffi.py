@@ -34,6 +34,7 @@ EXPORTS = [
 KH_EXEC_GRAPH, KH_EXEC_FUSED, KH_EXEC_UNFUSED = 0, 1, 2
 KH_NUM_KCLASS = 7
 KH_ERR_RANGE = -6
+KH_ERR_INTERNAL = -7
 KH_FLAG_ATTN_MERGE_IN_LAUNCH = 1
 KH_FLAG_ATTN_MERGE_FENCED = 2
 KH_FLAG_PREFILL_EXACT = 4

@@ -8,6 +8,8 @@
 //   kh_model_profile.hip  per-kernel / per-step timing entry points
 // gfx950 only.  No CPU fallback: every path launches HIP kernels.
 #pragma once
+#include <new>
+#include <thread>
 #include <stdint.h>
 
 #include <vector>
@@ -16,6 +18,26 @@
 #include "kh_common.h"
 
 namespace khm {
+// No C++ exception crosses the C ABI: the entry points that allocate host containers or start threads run their
+// body through this (std::bad_alloc -> hipErrorOutOfMemory, anything else -> KH_ERR_INTERNAL).
+template <class F>
+static inline int kh_api_guard(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return (int)hipErrorOutOfMemory;
+  } catch (...) {
+    return KH_ERR_INTERNAL;
+  }
+}
+// joins a helper thread on every way out of a scope (an exception while it runs would otherwise terminate)
+struct KhJoinOnExit {
+  std::thread& t;
+  ~KhJoinOnExit() {
+    if (t.joinable()) t.join();
+  }
+};
+
 struct LayerW {
   KhLin wq, wk, wv, wo, w1, w2, w3;
   const float* att_norm;

@@ -96,6 +96,7 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
     std::atomic<bool> abort_{false};
     auto worker = [&](int w) {
       for (size_t c = 0; c < nchunks; ++c) {
+        if (abort_.load(std::memory_order_relaxed)) return;
         while ((long)c >= released.load(std::memory_order_acquire)) {
           if (abort_.load(std::memory_order_relaxed)) return;
           std::this_thread::yield();
@@ -109,7 +110,13 @@ hipError_t upload_chunked(char* d_dst, const char* h_src, size_t n, hipStream_t 
       }
     };
     std::vector<std::thread> team;
-    for (int w = 0; w < NT; ++w) team.emplace_back(worker, w);
+    try {
+      team.reserve((size_t)NT);
+      for (int w = 0; w < NT; ++w) team.emplace_back(worker, w);
+    } catch (...) {  // a thread could not be started: the chunks would never fill - stop the ones that run
+      abort_.store(true);
+      e = hipErrorOutOfMemory;
+    }
     for (size_t c = 0; c < nchunks && e == hipSuccess; ++c) {
       while (filled[c].load(std::memory_order_acquire) < NT) std::this_thread::yield();
       const size_t off = c * CH, len = off + CH <= n ? CH : n - off;
@@ -463,16 +470,12 @@ extern "C" void kh_model_destroy(kh_model* m) {
   delete m;
 }
 
-extern "C" int kh_model_create_from_device_weights(const int32_t* h_header,
-                                                   const void* d_weight_data,
-                                                   size_t weight_nbytes,
-                                                   const kh_model_opts* opts, kh_model** out) {
-  if (!d_weight_data || !kh_aligned16(d_weight_data)) return KH_ERR_INVALID_ARG;
-  if (!out) return KH_ERR_INVALID_ARG;
-  *out = nullptr;
+static int create_from_device_weights_impl(const int32_t* h_header, const void* d_weight_data, size_t weight_nbytes,
+                                           const kh_model_opts* opts, kh_model** out) {
   kh_model* m = nullptr;
   int rc = new_model(h_header, opts, &m);
   if (rc != KH_OK) return rc;
+  *out = m;  // see create_from_host_image_impl
   if (weight_nbytes < expected_weight_bytes(m->cfg)) {
     kh_model_destroy(m);
     *out = nullptr;
@@ -490,18 +493,34 @@ extern "C" int kh_model_create_from_device_weights(const int32_t* h_header,
   *out = m;
   return rc;
 }
+extern "C" int kh_model_create_from_device_weights(const int32_t* h_header,
+                                                   const void* d_weight_data,
+                                                   size_t weight_nbytes,
+                                                   const kh_model_opts* opts, kh_model** out) {
+  if (!d_weight_data || !kh_aligned16(d_weight_data)) return KH_ERR_INVALID_ARG;
+  if (!out) return KH_ERR_INVALID_ARG;
+  *out = nullptr;
+  const int rc =
+      kh_api_guard([&] { return create_from_device_weights_impl(h_header, d_weight_data, weight_nbytes, opts, out); });
+  if (rc != KH_OK && *out) {  // only after an exception
+    kh_model_destroy(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
 
-extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbytes,
-                                               const kh_model_opts* opts, kh_model** out) {
-  if (!h_image || !opts || !out) return KH_ERR_INVALID_ARG;
+// *out holds the model from the moment it exists, so that the boundary below can release it when an exception
+// (host allocation, thread creation) cuts the construction short
+static int create_from_host_image_impl(const void* h_image, size_t nbytes, const kh_model_opts* opts,
+                                       kh_model** out) {
   const size_t hdr = opts->is_quant ? 32 : 28;
   if (nbytes < hdr) return KH_ERR_FORMAT;
   int32_t header[8] = {0};
   memcpy(header, h_image, hdr);
-  *out = nullptr;
   kh_model* m = nullptr;
   int rc = new_model(header, opts, &m);
   if (rc != KH_OK) return rc;
+  *out = m;
   const size_t need = expected_weight_bytes(m->cfg);
   if (nbytes - hdr < need) {
     kh_model_destroy(m);
@@ -533,6 +552,7 @@ extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbyte
     eu = hipSetDevice(dev);
     if (eu == hipSuccess) eu = upload_chunked(m->arena, (const char*)h_image + hdr, need, m->stream, &m->load_ms);
   });
+  KhJoinOnExit join_uploader{uploader};
   rc = finish_create(m, &sincos);
   uploader.join();
   if (rc == KH_OK && eu != hipSuccess) rc = (int)eu;
@@ -546,6 +566,17 @@ extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbyte
     m = nullptr;
   }
   *out = m;
+  return rc;
+}
+extern "C" int kh_model_create_from_host_image(const void* h_image, size_t nbytes,
+                                               const kh_model_opts* opts, kh_model** out) {
+  if (!h_image || !opts || !out) return KH_ERR_INVALID_ARG;
+  *out = nullptr;
+  const int rc = kh_api_guard([&] { return create_from_host_image_impl(h_image, nbytes, opts, out); });
+  if (rc != KH_OK && *out) {  // only after an exception: the failure paths of the body release the model themselves
+    kh_model_destroy(*out);
+    *out = nullptr;
+  }
   return rc;
 }
 
@@ -576,10 +607,15 @@ extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* 
   // (1.2 M PTEs for the 4.98 GB Llama-3.2-1B image: 60-80 ms measured) and nobody waits for it: a detached thread
   // unmaps and closes while the caller already decodes.
   const size_t len = (size_t)st.st_size;
-  std::thread([data, len, fd] {
+  try {
+    std::thread([data, len, fd] {
+      munmap(data, len);
+      close(fd);
+    }).detach();
+  } catch (...) {  // no helper thread to be had: unmap here
     munmap(data, len);
     close(fd);
-  }).detach();
+  }
   pc.lap("munmap handed to a helper thread");
   return rc;
 }

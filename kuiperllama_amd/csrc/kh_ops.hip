@@ -740,6 +740,7 @@ extern "C" const char* kh_error_string(int code) {
     case KH_ERR_FORMAT: return "malformed model image";
     case KH_ERR_NO_DEVICE: return "no HIP device";
     case KH_ERR_RANGE: return "token or position out of range";
+    case KH_ERR_INTERNAL: return "C++ exception inside the library (caught at the boundary)";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -34,6 +34,7 @@ def test_version_and_error_strings(lib):
     assert lib.kh_version() == 100
     assert _ffi.error_string(0) == "success"
     assert "invalid" in _ffi.error_string(-1)
+    assert "exception" in _ffi.error_string(_ffi.KH_ERR_INTERNAL)  # no C++ exception crosses the C ABI (kh_api_guard)
     assert lib.kh_kclass_name(3).decode() == "ffn13"
 
 
