@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""kh_model_create_from_file on an image in /dev/shm: whole-call and upload-only GB/s, three loads.
+"""kh_model_create_from_file on an image in /dev/shm: whole-call and upload-only GB/s.
+Loads 1-3 back to back (each right after the previous model's hipFree of weights + KV cache), load 4 after a pause:
+is a slow create the allocator handing back memory that is still being released?
 usage: tools/load_probe.py [workload]   (run on the GPU box)"""
 import json
 import os
@@ -21,14 +23,17 @@ n = int(img.numel())
 del img
 torch.cuda.empty_cache()
 try:
-    for i in range(3):
+    for i in range(4):
+        if i == 3:
+            time.sleep(3.0)
         t0 = time.perf_counter()
         m = KuiperModel.from_file(path, spec)
         wall = time.perf_counter() - t0
         up = m.load_ms
         words, _ = m.generate([1, 263], 8)
         m.close()
-        print(json.dumps({"workload": name, "GB": round(n / 1e9, 2), "create_ms": round(wall * 1e3, 1),
+        print(json.dumps({"load": i + 1, "after": "a 3-s pause" if i == 3 else ("the image's hipFree" if i == 0 else "the previous model's hipFree"),
+                          "workload": name, "GB": round(n / 1e9, 2), "create_ms": round(wall * 1e3, 1),
                           "GB/s": round(n / wall / 1e9, 1), "upload_ms": round(up, 1),
                           "upload_GB/s": round(n / up / 1e6, 1), "other_ms": round(wall * 1e3 - up, 1),
                           "words": words[:4]}), flush=True)
