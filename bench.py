@@ -21,9 +21,14 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
              algorithmic bytes per launch / its average launch duration measured with HIP
              events on the model's own stream (kh_model_profile_step) right after the timed
              region.  "step" adds the whole-token figure (bytes/token x tok/s).
-* cpu_baseline : the CPU oracle (oracle/, a port of the reference's CPU backend — the
-             reference's C++ cannot be built here) timed on this host's cores on a bounded
-             number of tokens of the same workload.
+* cpu_baseline : kind "reference" = the reference's OWN CPU backend (oracle/_ref/ref_cpu_model*:
+             its cpu/*.cpp kernels + model classes compiled where they lie over an Armadillo
+             stand-in on numpy's OpenBLAS) timed on this host's cores on a bounded number of
+             tokens of the same workload, its tokens compared with the GPU's; the oracle
+             (oracle/, the restatement the parity tests use) beside it as cpu_baseline.port,
+             and alone (kind "port") where the reference has no CPU path (int8).
+* layout   : both halves of the metric and their roofline fractions as scalars inside
+             `roofline` / `config` and again in `summary` at the end of the line (assemble_line).
 * other_configs : the remaining BASELINE.json configs (Qwen2.5-0.5B, TinyLlama-1.1B = the
              north-star floor of 60 tok/s, Llama-2-7B fp32 = one replica of config 5) measured
              briefly into the same line, each with a token check against a short oracle pass.
@@ -657,6 +662,92 @@ NORTH_STAR_FLOOR = {"config": "tinyllama-1.1b", "target_tok_s": 60.0,
                               "(/root/reference/readme.md:25: 60.34 tok/s, RTX 3060 Laptop)"}
 
 
+def _flat_first(d: dict) -> dict:
+    """Scalars before nested objects (key order is the print order): a reader that keeps only scalar members
+    of `roofline` / `config`, or only the head of a long object, still gets the numbers."""
+    return {**{k: v for k, v in d.items() if not isinstance(v, (dict, list))},
+            **{k: v for k, v in d.items() if isinstance(v, (dict, list))}}
+
+
+def assemble_line(spec, args, world, res, secondary, others, skipped, timing_backend) -> dict:
+    """The ONE JSON line.  Both halves of BASELINE.json's metric (Llama-3.2-1B fp32 and Llama-2-7B int8 decode
+    tok/s) and their roofline fractions are carried as SCALARS inside `roofline` and `config` (a record parser that
+    keeps the contract's objects but only the names of extra top-level keys loses `secondary` otherwise), the
+    contract's scalar keys come first, the bulky sections last, and `summary` repeats the scalars at the very end
+    (a tail of the line that lost its head still has them).  tests/test_bench_logic.py pins this layout."""
+    sec_ok = isinstance(secondary, dict) and "value" in secondary
+    sr = secondary["roofline"] if sec_ok else {}
+    summary = {
+        "value": res["value"], "ms_per_step": res["ms_per_step"],
+        "tok_s_128_steps": res.get("tok_s_128_steps"),
+        "kernel_frac": res["roofline"]["frac"], "step_frac": res["roofline"]["step"]["frac"],
+        "secondary_workload": secondary["config"]["workload"] if sec_ok else None,
+        "secondary_value": secondary["value"] if sec_ok else None,
+        "secondary_ms_per_step": secondary["ms_per_step"] if sec_ok else None,
+        "secondary_tok_s_128_steps": secondary.get("tok_s_128_steps") if sec_ok else None,
+        "secondary_kernel_frac": sr.get("frac"),
+        "secondary_step_frac": sr.get("step", {}).get("frac"),
+    }
+    roofline = dict(res["roofline"])
+    roofline["step_frac"] = summary["step_frac"]
+    roofline["step_achieved"] = res["roofline"]["step"]["achieved"]
+    roofline["secondary_frac"] = summary["secondary_kernel_frac"]
+    roofline["secondary_achieved"] = sr.get("achieved")
+    roofline["secondary_step_frac"] = summary["secondary_step_frac"]
+    roofline["secondary_step_achieved"] = sr.get("step", {}).get("achieved")
+    config = {"workload": f"{spec.name} greedy decode, batch 1, prompt {PROMPT}, "
+                          f"{args.steps} steps from pos 0 (demo/main.cpp generate)",
+              "parallelism": f"replicas{world} (no shard, no data-path collective; one process "
+                             f"per GPU, HIP_VISIBLE_DEVICES/LOCAL_RANK pinning)",
+              "timing_backend": timing_backend,
+              "exec": "hipGraph replay, 5L+2 fused HIP kernels per token",
+              "kv_cache_rows": spec.seq_len,
+              "tok_s_128_steps": summary["tok_s_128_steps"],
+              "secondary_workload": summary["secondary_workload"],
+              "secondary_value": summary["secondary_value"],
+              "secondary_ms_per_step": summary["secondary_ms_per_step"],
+              "secondary_tok_s_128_steps": summary["secondary_tok_s_128_steps"]}
+    line = {
+        "metric": "decode tokens/sec",
+        "value": res["value"], "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8 weights x f32 activations" if spec.quant else "f32",
+        "tok_s_128_steps": summary["tok_s_128_steps"],
+        "secondary_value": summary["secondary_value"],
+        "secondary_ms_per_step": summary["secondary_ms_per_step"],
+        "secondary_step_frac": summary["secondary_step_frac"],
+        "data": "synthetic via kuiperllama_amd.binfmt.synth_image (seeded torch RNG on the GPU, the "
+                "reference exporter's .bin byte layout and init std; not the reference exporter itself)",
+        "config": config,
+        "roofline": _flat_first(roofline),
+    }
+    if "cpu_baseline" in res:
+        line["cpu_baseline"] = _flat_first(res["cpu_baseline"])
+    line["replicas"] = res["replicas"]
+    line["runs"] = res.get("runs")
+    line["tok_s_128_steps_is"] = res.get("tok_s_128_steps_is")
+    line["latency_us_at_pos"] = res.get("latency_us_at_pos")
+    line["prefill"] = res.get("prefill")
+    if "long_context" in res:
+        line["long_context"] = res["long_context"]
+    if "load" in res:
+        line["load"] = res["load"]
+    if skipped:
+        line["skipped_sections"] = skipped
+    if secondary is not None:
+        line["secondary"] = secondary
+    if others:
+        line["other_configs"] = others
+        fl = others.get(NORTH_STAR_FLOOR["config"])
+        if fl and "value" in fl:
+            line["north_star_floor"] = dict(NORTH_STAR_FLOOR, tok_s=fl["value"],
+                                            met=bool(fl["value"] >= NORTH_STAR_FLOOR["target_tok_s"]),
+                                            tokens_match=fl.get("tokens_match"))
+    line["summary"] = summary
+    return line
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -749,45 +840,7 @@ def main(argv=None):
                 others[w] = {"error": repr(e)}
 
     if rank == 0:
-        line = {
-            "metric": "decode tokens/sec",
-            "value": res["value"], "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 weights x f32 activations" if spec.quant else "f32",
-            "data": "synthetic via kuiperllama_amd.binfmt.synth_image (seeded torch RNG on the GPU, the "
-                    "reference exporter's .bin byte layout and init std; not the reference exporter itself)",
-            "config": {"workload": f"{spec.name} greedy decode, batch 1, prompt {PROMPT}, "
-                                   f"{args.steps} steps from pos 0 (demo/main.cpp generate)",
-                       "parallelism": f"replicas{world} (no shard, no data-path collective; one process "
-                                      f"per GPU, HIP_VISIBLE_DEVICES/LOCAL_RANK pinning)",
-                       "timing_backend": replicas.backend_in_use(world),
-                       "exec": "hipGraph replay, 5L+2 fused HIP kernels per token",
-                       "kv_cache_rows": spec.seq_len},
-            "roofline": res["roofline"],
-            "replicas": res["replicas"],
-            "runs": res.get("runs"), "tok_s_128_steps": res.get("tok_s_128_steps"),
-            "tok_s_128_steps_is": res.get("tok_s_128_steps_is"),
-            "latency_us_at_pos": res.get("latency_us_at_pos"),
-            "prefill": res.get("prefill"),
-        }
-        if "long_context" in res:
-            line["long_context"] = res["long_context"]
-        if "load" in res:
-            line["load"] = res["load"]
-        if skipped:
-            line["skipped_sections"] = skipped
-        if "cpu_baseline" in res:
-            line["cpu_baseline"] = res["cpu_baseline"]
-        if secondary is not None:
-            line["secondary"] = secondary
-        if others:
-            line["other_configs"] = others
-            fl = others.get(NORTH_STAR_FLOOR["config"])
-            if fl and "value" in fl:
-                line["north_star_floor"] = dict(NORTH_STAR_FLOOR, tok_s=fl["value"],
-                                                met=bool(fl["value"] >= NORTH_STAR_FLOOR["target_tok_s"]),
-                                                tokens_match=fl.get("tokens_match"))
+        line = assemble_line(spec, args, world, res, secondary, others, skipped, replicas.backend_in_use(world))
         print(json.dumps(line), flush=True)
     replicas.shutdown(world)
 

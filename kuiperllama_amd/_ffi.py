@@ -189,6 +189,29 @@ def debug_get(key: str) -> Optional[str]:
 
 _HOOK_PREFIXES = ("KH_SHAPE_", "KH_ATTN_", "KH_PG_", "KH_PREFILL", "KH_RING")
 _ENV_MIRRORED = {}  # hook -> value, as last written into the table FROM os.environ by sync_env()
+_ENV_SEEDED = False
+
+
+def _seed_mirror(L) -> None:
+    """First sync: the library seeded its table from the KH_* environment when it was loaded.  Hooks that are in
+    the table AND were in the environment then are environment-owned from the start (value as in the table), so
+    that a variable removed from os.environ before the first sync_env() - monkeypatch.delenv - is cleared like
+    any other; a key that is in the table only (kh_debug_set before the first sync) stays the caller's."""
+    global _ENV_SEEDED
+    _ENV_SEEDED = True
+    n = L.kh_debug_list(None, 0)
+    if n <= 0:
+        return
+    buf = C.create_string_buffer(int(n) + 1)
+    L.kh_debug_list(buf, int(n) + 1)
+    for k in buf.value.decode().split("\n"):
+        if k and k.startswith(_HOOK_PREFIXES) and k in _ENV_AT_IMPORT:
+            v = L.kh_debug_get(k.encode())
+            if v is not None and v.decode() == _ENV_AT_IMPORT[k]:
+                _ENV_MIRRORED.setdefault(k, _ENV_AT_IMPORT[k])
+
+
+_ENV_AT_IMPORT = {k: v for k, v in os.environ.items() if k.startswith(_HOOK_PREFIXES)}
 
 
 def sync_env() -> None:
@@ -199,6 +222,8 @@ def sync_env() -> None:
     `os.environ[...] = ...` / `monkeypatch.setenv` keep working in tests and tools.  Only keys that came from
     the environment are managed: a variable that disappears from os.environ is cleared in the table, a hook
     set through debug_set() is left alone (an environment variable of the same name overrides it)."""
+    if not _ENV_SEEDED:
+        _seed_mirror(lib())
     want = {k: v for k, v in os.environ.items() if k.startswith(_HOOK_PREFIXES)}
     if want == _ENV_MIRRORED:  # nothing changed since the last call: no table walk per generate()
         return

@@ -540,6 +540,9 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
 //    a partition mode where the above has not been verified.
 __device__ __forceinline__ void attn_publish_barrier(bool fenced) {
   if (fenced) {
+    // every storing wave drains its stores here too: a workgroup-scope barrier need not wait for vmcnt, and the
+    // release fence below is issued by one lane only - with the wait the fenced form is a strict superset of the default
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

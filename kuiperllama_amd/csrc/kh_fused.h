@@ -131,6 +131,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_qkv(const KhQkvArgs a) {
   struct Aux {
     float fci, fcr, b0, b1;
   };
+  float rs = 1.f;  // RMS scale of x: set by the staging, applied in the epilogue
   auto pre = [&](int p) __attribute__((always_inline)) {
     int which, r0, r1, cidx;
     decode(p, which, r0, r1, cidx);
@@ -146,9 +147,10 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_qkv(const KhQkvArgs a) {
     if (lane != 0) return;
     int which, r0, r1, cidx;
     decode(p, which, r0, r1, cidx);
-    // matmul.cpp:74-77: bias added after the matmul, before RoPE (x + 0.f is exact)
-    s0 = s0 + x.b0;
-    s1 = s1 + x.b1;
+    // the RMS scale of the staged vector (kh_gemv.h::stage_vec), then matmul.cpp:74-77: bias added after
+    // the matmul, before RoPE (x + 0.f is exact)
+    s0 = rs * s0 + x.b0;
+    s1 = rs * s1 + x.b1;
     float* dst = sel3(which, q_out, kc + (size_t)pos * kv_dim, vc + (size_t)pos * kv_dim);
     if (which < 2) {
       const float v0 = s0, v1 = s1;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_qkv(const KhQkvArgs a) {
   };
   gemv_pairs<SPLIT, /*ROLL=*/QUANT>(g, xs, total, lane, red + KH_WAVES_MAX, pair, pre,
                               [&]() __attribute__((always_inline)) { st.issue(); },
-                              [&]() __attribute__((always_inline)) { st.finish(xs, eps, red); }, epi);
+                              [&]() __attribute__((always_inline)) { rs = st.finish(xs, eps, red); }, epi);
   KH_STAMP_FLUSH();
 }
 
@@ -208,7 +210,7 @@ __device__ __forceinline__ void gemv_res_body(const KhGemvResArgs& a, St& st, f3
   gemv_pairs<SPLIT, /*ROLL=*/false>(
       g, xs, a.K >> 1 /* K even, checked at model build */, lane, red + KH_WAVES_MAX, pair, pre,
       [&]() __attribute__((always_inline)) { st.issue(); },
-      [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
+      [&]() __attribute__((always_inline)) { (void)st.finish(xs, 0.f, red); }, epi);
 }
 template <bool QUANT, int U, int MAXV, int SPLIT>
 __global__ __launch_bounds__(KH_WG_MAX, 4) void k_gemv_res(const KhGemvResArgs a) {
@@ -404,12 +406,13 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_ffn13(const KhFfn13Args a) {
   const Gemv<QUANT, U> g(a.dim, a.gshift);
   Stager<true, QUANT, MAXV> st(a.x, a.ffn_norm, a.dim);
   auto pair = [&](int r) __attribute__((always_inline)) { return g.rows(a.w1.w, r, a.w3.w, r, a.w1.scales, a.w3.scales, a.dim); };
+  float rs = 1.f;  // RMS scale of x: set by the staging, applied in the epilogue
   auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
-    if (lane == 0) a.h[r] = swiglu1(s0, s1);
+    if (lane == 0) a.h[r] = swiglu1(rs * s0, rs * s1);
   };
   gemv_pairs<1, /*ROLL=*/false>(g, xs, a.hidden, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
-                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
+                       [&]() __attribute__((always_inline)) { rs = st.finish(xs, a.eps, red); }, epi);
   KH_STAMP_FLUSH();
 }
 
@@ -439,9 +442,12 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_cls(const KhClsArgs a) {
   auto pair = [&](int p) __attribute__((always_inline)) {
     return g.rows(a.wcls.w, 2 * p, a.wcls.w, r1_of(p), a.wcls.scales, a.wcls.scales, a.dim);
   };
+  float rs = 1.f;  // RMS scale of x: set by the staging, applied in the epilogue
   auto epi = [&](int p, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane != 0) return;
     const int r0 = 2 * p, r1 = r1_of(p);
+    s0 *= rs;
+    s1 *= rs;
     a.logits[r0] = s0;
     amax_merge(bv, bi, s0, r0);
     if (r1 != r0) {
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(KH_WG_MAX, 4) void k_cls(const KhClsArgs a) {
   gemv_pairs<1, /*ROLL=*/false>(g, xs, (a.vocab + 1) >> 1, lane, nullptr, pair,
                           [](int) __attribute__((always_inline)) { return NoAux{}; },
                        [&]() __attribute__((always_inline)) { st.issue(); },
-                       [&]() __attribute__((always_inline)) { st.finish(xs, a.eps, red); }, epi);
+                       [&]() __attribute__((always_inline)) { rs = st.finish(xs, a.eps, red); }, epi);
   // stage-1 argmax: one partial per workgroup (ties -> lowest index)
   int* redi = (int*)(red + 3 * KH_WAVES_MAX);
   __syncthreads();

@@ -27,14 +27,15 @@ __global__ __launch_bounds__(1024) void k_ffn13_ring(const KhFfn13Args a) {
   const Gemv<true, 1> g(dim, a.gshift);
   ST st(a.x, a.ffn_norm, xs, smem_raw + ring_lds_wraw_off(dim), dim);
   auto pair = [&](int r) __attribute__((always_inline)) { return g.rows(w1, r, w3, r, s1p, s3p, dim); };
+  float rs = 1.f;  // RMS scale of x: set by the staging, applied in the epilogue (as k_ffn13)
   auto epi = [&](int r, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
-    if (lane == 0) h[r] = swiglu1(s0, s1);
+    if (lane == 0) h[r] = swiglu1(rs * s0, rs * s1);
   };
   ring_pairs<1, R, BLOCKED>(
       dim, a.gshift, xs, a.hidden, lane, nullptr, smem_raw + ring_lds_off(dim, ST::kRawArea), pair,
       [](int) __attribute__((always_inline)) { return NoAux{}; },
       [&]() __attribute__((always_inline)) { st.issue(); },
-      [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
+      [&](bool exact) __attribute__((always_inline)) { rs = st.template finish<R * 4>(eps, red, exact); }, epi);
   KH_STAMP_FLUSH();
 }
 
@@ -56,9 +57,12 @@ __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
   int bi = 0x7fffffff;
   auto r1_of = [&](int p) __attribute__((always_inline)) { return 2 * p + 1 < vocab ? 2 * p + 1 : 2 * p; };
   auto pair = [&](int p) __attribute__((always_inline)) { return g.rows(w, 2 * p, w, r1_of(p), sc, sc, dim); };
+  float rs = 1.f;  // RMS scale of x: set by the staging, applied in the epilogue (as k_cls)
   auto epi = [&](int p, float s0, float s1, const NoAux&) __attribute__((always_inline)) {
     if (lane != 0) return;
     const int r0 = 2 * p, r1 = r1_of(p);
+    s0 *= rs;
+    s1 *= rs;
     logits[r0] = s0;
     amax_merge(bv, bi, s0, r0);
     if (r1 != r0) {
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(1024) void k_cls_ring(const KhClsArgs a) {
       dim, a.gshift, xs, (vocab + 1) >> 1, lane, nullptr, smem_raw + ring_lds_off(dim, ST::kRawArea), pair,
       [](int) __attribute__((always_inline)) { return NoAux{}; },
       [&]() __attribute__((always_inline)) { st.issue(); },
-      [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
+      [&](bool exact) __attribute__((always_inline)) { rs = st.template finish<R * 4>(eps, red, exact); }, epi);
   // stage-1 argmax: one partial per workgroup (ties -> lowest index), as k_cls; red[] / comb[] are free again
   int* redi = (int*)(red + KH_WAVES_MAX);
   __syncthreads();

@@ -362,49 +362,76 @@ __device__ __forceinline__ void gemv_pairs(const G& g, const f32x4* xs, int tota
 struct NoAux {};
 
 // ---------------------------------------------------------------------------------------------
-// Stage a vector into LDS (all 256 threads), optionally RMS-normalising it on the way:
-//   xs = w_norm * (x * 1/sqrt(mean(x^2)+eps))           (cpu/rmsnorm_kernel.cpp:24-32)
+// Stage a vector into LDS (all threads of the workgroup).  With NORM the vector is the input of an RMSNorm
+//   xn = w_norm * (x * rs),  rs = 1/sqrt(mean(x^2)+eps)          (cpu/rmsnorm_kernel.cpp:24-32)
+// whose SCALE is applied behind the dot product: LDS receives g = w_norm * x as soon as x is there, the
+// per-wave sums of squares travel through `red` under the SAME barrier that publishes g, every thread
+// forms rs behind that barrier, and the epilogue of the GEMV multiplies:  W . xn = rs * (W . g).
+// One barrier between the vector's arrival and the first FMA instead of three (the block sum's two + the
+// LDS write's), nothing but a multiply in front of the LDS write.  The decode kernels, the B-token
+// prefill (kh_prefill.h) and the int8 ring kernels (kh_q8ring.h) all stage this way, so they stay
+// bit-identical to each other; against the oracle's w * (rs * x) the result differs by fp32 round-off
+// (tests: tokens equal, logits <= 4e-5).
 // Every workgroup recomputes the norm redundantly from the L2-resident x (8-16 KiB): cheaper
 // than a separate single-block launch + kernel boundary (reference: row_rmsnorm_f32, 1 block).
-// LAYOUT_Q8 selects the q8_slot() arrangement.  red = LDS float[4].
+// LAYOUT_Q8 selects the q8_slot() arrangement.  red = LDS float[KH_WAVES_MAX].
+
+// The barrier of a NORM staging and the scale behind it: per-thread partial `ss` -> wave sum -> red[wave]
+// -> __syncthreads (also publishes the staged vector) -> red[0] + red[1] + ... in wave order.
+__device__ __forceinline__ float stage_rs(float ss, int M, float eps, float* red) {
+  static_assert(KH_WAVES_MAX == 8, "red[] is read as two float4");
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  // all eight words in two reads, words of absent waves (never written) dropped by a select: no branch, no
+  // dependent LDS round trips (the clamped-index form of block_sum compiles to a ladder of scalar branches)
+  const f32x4 ra = ((const f32x4*)red)[0], rb = ((const f32x4*)red)[1];
+  const int n = kh_nwaves();
+  float r = 0.f;
+  r += ra.x;
+  r += n > 1 ? ra.y : 0.f;
+  r += n > 2 ? ra.z : 0.f;
+  r += n > 3 ? ra.w : 0.f;
+  r += n > 4 ? rb.x : 0.f;
+  r += n > 5 ? rb.y : 0.f;
+  r += n > 6 ? rb.z : 0.f;
+  r += n > 7 ? rb.w : 0.f;
+  return 1.0f / sqrtf(r / (float)M + eps);
+}
 template <bool NORM, bool LAYOUT_Q8>
-__device__ __forceinline__ void stage_vec(const float* __restrict__ x,
-                                          const float* __restrict__ wnorm, f32x4* xs, int M,
-                                          float eps, float* red) {
+__device__ __forceinline__ float stage_vec(const float* __restrict__ x,
+                                           const float* __restrict__ wnorm, f32x4* xs, int M,
+                                           float eps, float* red) {
   const int M4 = M >> 2;
   const f32x4* x4 = (const f32x4*)x;
-  float rs = 1.f;
-  if (NORM) {
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < M4; i += kh_wg()) {
-      const f32x4 v = x4[i];
-      ss = fma4(v, v, ss);
-    }
-    ss = block_sum(ss, red);
-    const float mean = ss / (float)M + eps;
-    rs = 1.0f / sqrtf(mean);
-  }
   const f32x4* w4 = (const f32x4*)wnorm;
   const int M16 = M >> 4;
+  float ss = 0.f;
   for (int i = threadIdx.x; i < M4; i += kh_wg()) {
     f32x4 v = x4[i];
     if (NORM) {
+      ss = fma4(v, v, ss);
       const f32x4 w = w4[i];
-      v.x = w.x * (rs * v.x);
-      v.y = w.y * (rs * v.y);
-      v.z = w.z * (rs * v.z);
-      v.w = w.w * (rs * v.w);
+      v.x = w.x * v.x;
+      v.y = w.y * v.y;
+      v.z = w.z * v.z;
+      v.w = w.w * v.w;
     }
     xs[LAYOUT_Q8 ? q8_slot(i, M16) : i] = v;
   }
+  if constexpr (NORM) return stage_rs(ss, M, eps, red);
   __syncthreads();
+  return 1.f;
 }
 
 // Two-phase staging used by gemv_pairs: issue() puts MAXV float4 per thread of x (and of the
-// norm weight) in flight, finish() reduces / normalises / writes LDS.  MAXV is a COMPILE-TIME
+// norm weight) in flight, finish() writes LDS and returns the RMS scale.  MAXV is a COMPILE-TIME
 // choice (straight-line code between the x loads and their use, otherwise the compiler's
-// waitcnt merge degrades to vmcnt(0) = "wait for the weights too"):
-//   MAXV = 4  vectors up to 16 floats per thread (4096 at 256 threads: dim of every BASELINE config)
+// waitcnt merge degrades to vmcnt(0) = "wait for the weights too"), the smallest that covers the
+// vector (kh_stage_maxv: a slot beyond the vector is still a load instruction - of element 0 - on the
+// CU's address path; Llama-3.2-1B's 2048-float vector needs 2 per thread at 256 threads, 1 at 512):
+//   MAXV = 1 / 2 / 4  vectors up to 4 / 8 / 16 floats per thread (4096 at 256 threads: dim of every
+//             BASELINE config)
 //   MAXV = 6  up to 24 floats per thread (12288 at 512 threads: the 11008-float hidden vector of
 //             Llama-2-7B's w2; k_gemv_res only)
 //   MAXV = 0  any length: single-phase stage_vec AFTER the first weight loads were issued - its x
@@ -433,15 +460,15 @@ struct Stager {
       }
     }
   }
-  __device__ __forceinline__ void finish(f32x4* xs, float eps, float* red) {
+  // returns rs (1 without NORM): the caller's epilogue multiplies its dot products by it
+  __device__ __forceinline__ float finish(f32x4* xs, float eps, float* red) {
     if constexpr (MAXV == 0) {
-      stage_vec<NORM, LAYOUT_Q8>(x, wnorm, xs, M, eps, red);
+      return stage_vec<NORM, LAYOUT_Q8>(x, wnorm, xs, M, eps, red);
     } else {
       const int M4 = M >> 2, M16 = M >> 4;
-      float rs = 1.f;
       KH_STAMP(5);
+      float ss = 0.f;
       if (NORM) {
-        float ss = 0.f;
 #pragma unroll
         for (int v = 0; v < MAXV; ++v) {
           const float t = fma4(xv[v], xv[v], 0.f);
@@ -451,9 +478,6 @@ struct Stager {
         asm volatile("" :: "v"(ss));  // the stamp below is taken once the vector has arrived
 #endif
         KH_STAMP(6);
-        ss = block_sum(ss, red);
-        rs = 1.0f / sqrtf(ss / (float)M + eps);
-        KH_STAMP(7);
       }
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
@@ -461,18 +485,33 @@ struct Stager {
         if (i < M4) {
           f32x4 t = xv[v];
           if (NORM) {
-            t.x = wv[v].x * (rs * t.x);
-            t.y = wv[v].y * (rs * t.y);
-            t.z = wv[v].z * (rs * t.z);
-            t.w = wv[v].w * (rs * t.w);
+            t.x = wv[v].x * t.x;
+            t.y = wv[v].y * t.y;
+            t.z = wv[v].z * t.z;
+            t.w = wv[v].w * t.w;
           }
           xs[LAYOUT_Q8 ? q8_slot(i, M16) : i] = t;
         }
       }
+      if (NORM) {
+        const float rs = stage_rs(ss, M, eps, red);
+        KH_STAMP(7);
+        return rs;
+      }
       __syncthreads();
+      return 1.f;
     }
   }
 };
+// float4 of the vector per staging thread: the smallest of 1 / 2 / 4 / 6 that covers M (0: single-phase staging)
+// does the 4-deep in-register staging cover M?  (the op-level kernels, the B-token prefill and the int8 ring
+// kernels use that depth whatever the length; a slot beyond the vector adds an exact 0 to the sum of
+// squares, so every depth that covers the vector stages the same bits)
+static inline bool kh_stage_fits4(int M, int wg = KH_WG) { return M <= 4 * 4 * wg; }
+#ifndef KH_STAGE_MAXV_MIN  // experiment hook (profiles/r6_staging_ab.txt): 4 = the depth of rounds 1-5
+#define KH_STAGE_MAXV_MIN 1
+#endif
 static inline int kh_stage_maxv(int M, int wg = KH_WG) {
-  return M <= 4 * 4 * wg ? 4 : (M <= 6 * 4 * wg ? 6 : 0);
+  if (KH_STAGE_MAXV_MIN >= 4 && M <= 4 * 4 * wg) return 4;
+  return M <= 1 * 4 * wg ? 1 : (M <= 2 * 4 * wg ? 2 : (M <= 4 * 4 * wg ? 4 : (M <= 6 * 4 * wg ? 6 : 0)));
 }

@@ -69,6 +69,7 @@ struct kh_model {
   int32_t* part_idx = nullptr;
   int nparts = 0;
   float load_ms = 0.f;      // host image -> HBM upload time (kh_model_get_load_ms)
+  std::thread unmap_thread;  // kh_model_create_from_file: munmap of the file off the critical path, joined by destroy
   void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
   int attn_ns = 1;
   int attn_ns_g = 0;        // GQA long-context path: splits per KV group (0 = path off)

@@ -446,6 +446,7 @@ int new_model(const int32_t* h_header, const kh_model_opts* opts, kh_model** out
 // =============================================================================================
 extern "C" void kh_model_destroy(kh_model* m) {
   if (!m) return;
+  if (m->unmap_thread.joinable()) m->unmap_thread.join();  // kh_model_create_from_file's munmap helper
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   destroy_step_graphs(m);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -604,15 +605,22 @@ extern "C" int kh_model_create_from_file(const char* path, const kh_model_opts* 
   const int rc = kh_model_create_from_host_image(data, (size_t)st.st_size, opts, out);
   pc.lap("create_from_host_image");
   // Tearing down the page tables of a multi-GB mapping whose every page was touched costs tens of milliseconds
-  // (1.2 M PTEs for the 4.98 GB Llama-3.2-1B image: 60-80 ms measured) and nobody waits for it: a detached thread
-  // unmaps and closes while the caller already decodes.
+  // (1.2 M PTEs for the 4.98 GB Llama-3.2-1B image: 60-80 ms measured) and nobody waits for it: a helper thread
+  // unmaps and closes while the caller already decodes.  The thread belongs to the model and kh_model_destroy joins
+  // it, so no code of this library runs behind the caller's back once every model is destroyed (dlclose-safe).
   const size_t len = (size_t)st.st_size;
-  try {
-    std::thread([data, len, fd] {
-      munmap(data, len);
-      close(fd);
-    }).detach();
-  } catch (...) {  // no helper thread to be had: unmap here
+  bool handed = false;
+  if (rc == KH_OK && out && *out) {
+    try {
+      (*out)->unmap_thread = std::thread([data, len, fd] {
+        munmap(data, len);
+        close(fd);
+      });
+      handed = true;
+    } catch (...) {  // no helper thread to be had: unmap here
+    }
+  }
+  if (!handed) {
     munmap(data, len);
     close(fd);
   }

@@ -17,11 +17,11 @@ using namespace khm;
 
 namespace khm {
 // The B-token kernels mirror the decode kernels' arithmetic only for the staging variant the
-// decode path uses at these sizes (in-register, MAXV = 4) and for the fast attention core.
+// decode path uses at these sizes (in-register, at most 4 float4 per thread) and for the fast attention core.
 bool prefill_supported(const kh_model* m) {
   const kh_config& c = m->cfg;
   if (c.head_size <= 32) return false;
-  if (kh_stage_maxv(c.dim, m->sh_qkv.wg) != 4 || kh_stage_maxv(c.dim, m->sh_ffn.wg) != 4) return false;
+  if (!kh_stage_fits4(c.dim, m->sh_qkv.wg) || !kh_stage_fits4(c.dim, m->sh_ffn.wg)) return false;
   if (m->sh_qkv.split > 2 || m->sh_ffn.split != 1) return false;
   if (pf_lds_bytes(c.is_quant, c.dim, 4) > 160 * 1024) return false;
   if (pf_lds_bytes(c.is_quant, c.hidden_dim, 2) > 160 * 1024) return false;

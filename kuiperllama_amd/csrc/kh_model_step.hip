@@ -110,6 +110,10 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
   do {                                                      \
     if ((MV) == 4)                                          \
       KH_L3(KERNEL, Q, UU, 4, __VA_ARGS__);                 \
+    else if ((MV) == 2)                                     \
+      KH_L3(KERNEL, Q, UU, 2, __VA_ARGS__);                 \
+    else if ((MV) == 1)                                     \
+      KH_L3(KERNEL, Q, UU, 1, __VA_ARGS__);                 \
     else                                                    \
       KH_L3(KERNEL, Q, UU, 0, __VA_ARGS__);                 \
   } while (0)
@@ -126,6 +130,10 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
   do {                                                      \
     if ((MV) == 4)                                          \
       KH_SEL_SP4(KERNEL, Q, UU, 4, SP, __VA_ARGS__);        \
+    else if ((MV) == 2)                                     \
+      KH_SEL_SP4(KERNEL, Q, UU, 2, SP, __VA_ARGS__);        \
+    else if ((MV) == 1)                                     \
+      KH_SEL_SP4(KERNEL, Q, UU, 1, SP, __VA_ARGS__);        \
     else                                                    \
       KH_SEL_SP4(KERNEL, Q, UU, 0, SP, __VA_ARGS__);        \
   } while (0)
@@ -559,17 +567,23 @@ void plan_decode_shapes(bool quant, int dim, int hidden_dim, int kv_dim, int voc
 void plan_ring(bool quant, int dim, int hidden_dim, int vocab_size, int group_size, kh_model::RingPlan* out) {
   *out = kh_model::RingPlan();
   if (!quant || dbg_off("KH_RING")) return;
-  if (dim % 16 != 0 || kh_stage_maxv(dim, KH_WG) != 4) return;
+  if (dim % 16 != 0 || !kh_stage_fits4(dim, KH_WG)) return;
   if (group_size < 16 || (group_size & (group_size - 1)) != 0 || dim % group_size != 0) return;
   if (ring_lds_bytes(dim, false, KH_WAVES_PER_WG, 2) > 64 * 1024) return;  // no dynamic-LDS opt-in on this path
   auto grid_of = [](int items) {
     const int need = (items + KH_WAVES_PER_WG - 1) / KH_WAVES_PER_WG;
     return need < 512 ? need : 512;
   };
-  out->ffn_r = 2;
-  out->ffn_grid = grid_of(hidden_dim);
-  out->cls_r = 2;
-  out->cls_grid = grid_of((vocab_size + 1) / 2);
+  // a KH_SHAPE_FFN / KH_SHAPE_CLS hook asks for a specific register-tile launch: honour it (the B-token prefill
+  // follows the same hook, and its bit-identity with decode needs the same workgroup width on both sides)
+  if (!dbg("KH_SHAPE_FFN")) {
+    out->ffn_r = 2;
+    out->ffn_grid = grid_of(hidden_dim);
+  }
+  if (!dbg("KH_SHAPE_CLS")) {
+    out->cls_r = 2;
+    out->cls_grid = grid_of((vocab_size + 1) / 2);
+  }
 }
 extern "C" int kh_plan_decode_ring(int32_t dim, int32_t hidden_dim, int32_t vocab_size, int32_t is_quant,
                                    int32_t group_size, int32_t* out4) {

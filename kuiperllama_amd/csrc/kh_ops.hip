@@ -5,6 +5,7 @@
 // meaning as the reference's CUDA kernels, raw device pointers instead of tensor::Tensor.
 // The fused decode path (kh_model_step.hip) reuses the same device cores (kh_gemv.h, kh_attn.h).
 #include "kh_attn.h"
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_f32(const float* __restrict__ 
     if (r1 != r0) y[r1] = s1 * scale;
   };
   gemv_pairs<1, /*ROLL=*/false>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
-                       [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
+                       [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { (void)st.finish(xs, 0.f, red); }, epi);
 }
 
 // any M / any alignment (also M too large for LDS): wave per row, scalar lane-strided loads
@@ -151,7 +152,7 @@ extern "C" int kh_matmul_f32(const float* x, const float* w, float* y, int32_t M
   const int per_lane = (M / 4 + KH_WAVE - 1) / KH_WAVE;
 #define KH_MM(UU, MV) \
   hipLaunchKernelGGL((k_matmul_f32<UU, MV>), dim3(grid), dim3(KH_WG), lds, s, x, w, y, M, K, scale)
-  const bool inreg = kh_stage_maxv(M) == 4;
+  const bool inreg = kh_stage_fits4(M);
   if (per_lane >= 8) {
     if (inreg) KH_MM(8, 4); else KH_MM(8, 0);
   } else if (per_lane >= 3) {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(KH_WG) void k_matmul_q8(const float* __restrict__ x
     if (r1 != r0) y[r1] = s1;
   };
   gemv_pairs<1, /*ROLL=*/false>(g, xs, (K + 1) >> 1, lane, nullptr, pair, [](int) __attribute__((always_inline)) { return NoAux{}; },
-                      [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { st.finish(xs, 0.f, red); }, epi);
+                      [&]() __attribute__((always_inline)) { st.issue(); }, [&]() __attribute__((always_inline)) { (void)st.finish(xs, 0.f, red); }, epi);
 }
 
 // literal restatement of the reference formula for any M/group/alignment
@@ -239,7 +240,7 @@ extern "C" int kh_matmul_q8(const float* x, const int8_t* w8, const float* scale
 #define KH_MMQ(UU, MV)                                                                        \
   hipLaunchKernelGGL((k_matmul_q8<UU, MV>), dim3(grid), dim3(KH_WG), lds, s, x, w8, scales, gshift, \
                      y, M, K)
-  const bool inreg = kh_stage_maxv(M) == 4;
+  const bool inreg = kh_stage_fits4(M);
   if (per_lane >= 3) {
     if (inreg) KH_MMQ(4, 4); else KH_MMQ(4, 0);
   } else {
@@ -686,42 +687,47 @@ extern "C" int kh_argmax_f32(const float* logits, int64_t n, int32_t* d_out_inde
 // The reference's sampler path (ArgmaxSampler::sample -> argmax_kernel_cu, argmax_kernel.cu:53-77) allocates 8 bytes
 // per token and never frees them; rounds 1-4 of this library allocated and freed 4 bytes per call, i.e. a
 // device-wide synchronisation per token.  One 4-byte device word per (device, stream), created on first use and
-// kept for the life of the process (a few bytes per stream ever used; calls on one stream are serialised by the
-// stream itself, calls on different streams use different words).
+// kept for the life of the process (a few bytes per stream ever used).  Calls on different streams use different
+// words; two host threads calling on the SAME stream (the null stream, say) are serialised by the word's own mutex,
+// held from the kernel launch to the stream synchronisation - otherwise kernel A, kernel B, copy A, copy B would hand
+// caller A the index of B's logits.
 namespace {
 struct ArgmaxSlot {
   int device;
   void* stream;
   int32_t* d;
+  std::mutex busy;
+  ArgmaxSlot(int dev, void* s, int32_t* p) : device(dev), stream(s), d(p) {}
 };
 std::mutex g_argmax_mu;
-std::vector<ArgmaxSlot> g_argmax_slots;
-int argmax_slot(void* stream, int32_t** out) {
+std::deque<ArgmaxSlot> g_argmax_slots;  // deque: slots never move once handed out
+int argmax_slot(void* stream, ArgmaxSlot** out) {
   int dev = 0;
   KH_CHECK_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> g(g_argmax_mu);
-  for (const auto& s : g_argmax_slots)
+  for (auto& s : g_argmax_slots)
     if (s.device == dev && s.stream == stream) {
-      *out = s.d;
+      *out = &s;
       return KH_OK;
     }
   int32_t* d = nullptr;
   KH_CHECK_HIP(hipMalloc((void**)&d, sizeof(int32_t)));
-  g_argmax_slots.push_back({dev, stream, d});
-  *out = d;
+  g_argmax_slots.emplace_back(dev, stream, d);
+  *out = &g_argmax_slots.back();
   return KH_OK;
 }
 }  // namespace
 extern "C" int kh_argmax_f32_host(const float* logits, int64_t n, int64_t* h_out_index,
                                   void* stream) {
   if (!h_out_index) return KH_ERR_INVALID_ARG;
-  int32_t* d = nullptr;
-  int rc = argmax_slot(stream, &d);
+  ArgmaxSlot* slot = nullptr;
+  int rc = argmax_slot(stream, &slot);
   if (rc != KH_OK) return rc;
-  rc = kh_argmax_f32(logits, n, d, stream);
+  std::lock_guard<std::mutex> busy(slot->busy);
+  rc = kh_argmax_f32(logits, n, slot->d, stream);
   int32_t h = -1;
   if (rc == KH_OK) {
-    hipError_t e = hipMemcpyAsync(&h, d, sizeof(int32_t), hipMemcpyDeviceToHost,
+    hipError_t e = hipMemcpyAsync(&h, slot->d, sizeof(int32_t), hipMemcpyDeviceToHost,
                                   (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     rc = e == hipSuccess ? KH_OK : (int)e;

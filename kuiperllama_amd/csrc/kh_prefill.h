@@ -11,7 +11,8 @@
 //     chunks l, l+64, l+128, ... of its column range whatever U is), with the same SPLIT
 //     partition and the same fixed-order combine;
 //   * RMS-norm statistics use the same per-thread partition and the same reduction order as
-//     Stager<.., MAXV = 4> of the decode kernels (same workgroup width);
+//     Stager of the decode kernels (same workgroup width), the vector is staged as w_norm * x and the
+//     scale multiplies the dot product in the epilogue, as there;
 //   * epilogues (bias, RoPE, SwiGLU, residual) are the same expressions;
 //   * attention is the decode kernel itself, one grid slice per token.
 // tests/test_model_gpu.py::test_prefill_* compares cache rows and the following logits bit for bit.
@@ -208,13 +209,14 @@ __device__ __forceinline__ void gemv_pairs_b(const Gemv<QUANT, U>& g, const f32x
 }
 
 // ---- staging of B vectors -----------------------------------------------------------------------
-// NORM: the arithmetic of Stager<true, .., 4>::finish, token by token (same per-thread partial
-// sums, same wave/LDS reduction order); the loads of all B tokens are issued before the first
-// reduction, and the B block sums share their two barriers.  x: [B][src_stride] floats.
+// NORM: the arithmetic of Stager<true, .., MAXV>::finish, token by token (same per-thread partial sums - a slot
+// beyond the vector adds 0 whatever MAXV is -, same wave / LDS reduction order, g = w_norm * x into LDS, the
+// scale rs[b] handed to the epilogue); the B sums of squares share ONE barrier with the LDS writes.
+// x: [B][src_stride] floats.
 template <bool LAYOUT_Q8, int B>
 __device__ __forceinline__ void pf_stage_norm(const float* x, size_t src_stride,
                                               const float* wnorm, f32x4* xs, int xstride, int M,
-                                              float eps, float* red /*[KH_WAVES_MAX*B]*/) {
+                                              float eps, float* red /*[KH_WAVES_MAX*B]*/, float (&rs)[B]) {
   constexpr int MAXV = 4;
   constexpr int TB = 2;  // tokens staged per round (register footprint: TB*MAXV float4)
   static_assert(B % TB == 0, "B must be a multiple of the staging batch");
@@ -239,7 +241,6 @@ __device__ __forceinline__ void pf_stage_norm(const float* x, size_t src_stride,
         const int i = threadIdx.x + v * wg;
         xv[t][v] = ((const f32x4*)(x + (size_t)(b0 + t) * src_stride))[i < M4 ? i : 0];
       }
-    float ss[TB];
 #pragma unroll
     for (int t = 0; t < TB; ++t) {
       float s = 0.f;
@@ -250,34 +251,29 @@ __device__ __forceinline__ void pf_stage_norm(const float* x, size_t src_stride,
       }
       s = wave_sum(s);
       if (lane == 0) red[wave * B + b0 + t] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < TB; ++t) {
-      float r = 0.f;
-#pragma unroll
-      for (int w = 0; w < KH_WAVES_MAX; ++w) r += w < n ? red[(w < n ? w : 0) * B + b0 + t] : 0.f;
-      ss[t] = r;
-    }
-#pragma unroll
-    for (int t = 0; t < TB; ++t) {
-      const float rs = 1.0f / sqrtf(ss[t] / (float)M + eps);
       f32x4* xb = xs + (size_t)(b0 + t) * xstride;
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
         const int i = threadIdx.x + v * wg;
         if (i < M4) {
           f32x4 q = xv[t][v];
-          q.x = wv[v].x * (rs * q.x);
-          q.y = wv[v].y * (rs * q.y);
-          q.z = wv[v].z * (rs * q.z);
-          q.w = wv[v].w * (rs * q.w);
+          q.x = wv[v].x * q.x;
+          q.y = wv[v].y * q.y;
+          q.z = wv[v].z * q.z;
+          q.w = wv[v].w * q.w;
           xb[LAYOUT_Q8 ? q8_slot(i, M16) : i] = q;
         }
       }
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_MAX; ++w) r += w < n ? red[(w < n ? w : 0) * B + b] : 0.f;
+    rs[b] = 1.0f / sqrtf(r / (float)M + eps);
+  }
 }
 // plain copy (inputs of wo / w2): no arithmetic, any length
 template <bool LAYOUT_Q8, int B>
@@ -399,6 +395,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_pf_qkv(const KhPfQkvArgs a) {
     x.b1 = bias ? bias[r1] : 0.f;
     return x;
   };
+  float rs[B];  // RMS scale per token: set by the staging, applied in the epilogue (as k_qkv)
   auto epi = [&](int p, const float (&s0)[B], const float (&s1)[B], const Aux& x)
       __attribute__((always_inline)) {
     if (lane != 0) return;
@@ -407,7 +404,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_pf_qkv(const KhPfQkvArgs a) {
 #pragma unroll
     for (int b = 0; b < B; ++b) {
       if (b >= nvalid) break;
-      float v0 = s0[b] + x.b0, v1 = s1[b] + x.b1;
+      float v0 = rs[b] * s0[b] + x.b0, v1 = rs[b] * s1[b] + x.b1;
       const size_t row = (size_t)(pos0 + b) * kv_dim;
       float* dst = sel3(which, Qo + (size_t)b * dim, kc + row, vc + row);
       if (which < 2) {
@@ -422,7 +419,7 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_pf_qkv(const KhPfQkvArgs a) {
   gemv_pairs_b<QUANT, U, SPLIT, B>(
       g, xs, xstride, total, lane, comb, pair, pre,
       [&]() __attribute__((always_inline)) {
-        pf_stage_norm<QUANT, B>(X, (size_t)dim, att_norm, xs, xstride, dim, eps, red);
+        pf_stage_norm<QUANT, B>(X, (size_t)dim, att_norm, xs, xstride, dim, eps, red, rs);
       },
       epi);
 }
@@ -452,18 +449,19 @@ __global__ __launch_bounds__(KH_WG_MAX) void k_pf_ffn13(const KhPfFfn13Args a) {
   const int lane = threadIdx.x & 63;
   const Gemv<QUANT, U> g(dim, a.gshift);
   auto pair = [&](int r) __attribute__((always_inline)) { return g.rows(w1, r, w3, r, s1p, s3p, dim); };
+  float rs[B];  // RMS scale per token: set by the staging, applied in the epilogue (as k_ffn13)
   auto epi = [&](int r, const float (&s0)[B], const float (&s1)[B], const NoAux&)
       __attribute__((always_inline)) {
     if (lane != 0) return;
 #pragma unroll
     for (int b = 0; b < B; ++b)
-      if (b < nvalid) H[(size_t)b * hidden + r] = swiglu1(s0[b], s1[b]);
+      if (b < nvalid) H[(size_t)b * hidden + r] = swiglu1(rs[b] * s0[b], rs[b] * s1[b]);
   };
   gemv_pairs_b<QUANT, U, 1, B>(
       g, xs, xstride, hidden, lane, nullptr, pair,
       [](int) __attribute__((always_inline)) { return NoAux{}; },
       [&]() __attribute__((always_inline)) {
-        pf_stage_norm<QUANT, B>(X, (size_t)dim, ffn_norm, xs, xstride, dim, eps, red);
+        pf_stage_norm<QUANT, B>(X, (size_t)dim, ffn_norm, xs, xstride, dim, eps, red, rs);
       },
       epi);
 }

@@ -36,20 +36,28 @@
 __device__ __forceinline__ unsigned kh_lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
+// M0 (the LDS destination of an LDS-DMA operation) is written inside the statements below and named in their
+// clobber lists, so the compiler sees a definition of M0 there and cannot carry a value of its own in M0 across
+// them.  M0 is a reserved register of the AMDGPU backend (never allocated, written by the compiler only right in
+// front of the instruction that consumes it), which is what -Winline-asm remarks on; nothing is expected to be
+// "preserved".
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 // 64 lanes x 16 B from (base + voff[lane]) to LDS [dst + 16 * lane]; dst is wave-uniform.  Weights: read once, nt.
 __device__ __forceinline__ void dma_x4(const void* base, unsigned voff, unsigned dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
                :
                : "v"(voff), "s"(base), "s"(dst)
-               : "memory");
+               : "memory", "m0");
 }
 // 64 lanes x 4 B to LDS [dst + 4 * lane]
 __device__ __forceinline__ void dma_x1(const void* base, unsigned voff, unsigned dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
                :
                : "v"(voff), "s"(base), "s"(dst)
-               : "memory");
+               : "memory", "m0");
 }
+#pragma clang diagnostic pop
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
@@ -93,8 +101,9 @@ struct StagerAsm {
       if (NORM) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[v]) : "v"(off), "s"(wnorm) : "memory");
     }
   }
+  // returns the RMS scale (1 without NORM), as Stager::finish
   template <int YOUNGER>
-  __device__ __forceinline__ void finish(float eps, float* red, bool exact) {
+  __device__ __forceinline__ float finish(float eps, float* red, bool exact) {
     if (exact)
       wait_vm<YOUNGER>();
     else
@@ -105,16 +114,13 @@ struct StagerAsm {
       if (NORM) asm volatile("" : "+v"(wv[v]));
     }
     const int M4 = M >> 2, M16 = M >> 4;
-    float rs = 1.f;
+    float ss = 0.f;
     if (NORM) {
-      float ss = 0.f;
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
         const float t = fma4(xv[v], xv[v], 0.f);
         ss += (threadIdx.x + v * kh_wg() < M4) ? t : 0.f;
       }
-      ss = block_sum(ss, red);
-      rs = 1.0f / sqrtf(ss / (float)M + eps);
     }
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) {
@@ -122,15 +128,17 @@ struct StagerAsm {
       if (i < M4) {
         f32x4 t = xv[v];
         if (NORM) {
-          t.x = wv[v].x * (rs * t.x);
-          t.y = wv[v].y * (rs * t.y);
-          t.z = wv[v].z * (rs * t.z);
-          t.w = wv[v].w * (rs * t.w);
+          t.x = wv[v].x * t.x;
+          t.y = wv[v].y * t.y;
+          t.z = wv[v].z * t.z;
+          t.w = wv[v].w * t.w;
         }
         xs[q8_slot(i, M16)] = t;
       }
     }
+    if (NORM) return stage_rs(ss, M, eps, red);
     __syncthreads();
+    return 1.f;
   }
 };
 

@@ -106,6 +106,17 @@ def test_debug_hooks_live_in_one_table_not_in_getenv(lib, monkeypatch):
     monkeypatch.setenv("KH_RING", "0")
     assert _ffi.plan_decode_ring(4096, 11008, 32000, True)["ffn13"]["slots"] == 0
     monkeypatch.delenv("KH_RING")
+    # a KH_SHAPE_FFN / KH_SHAPE_CLS hook names a register-tile launch: the ring must not take that launch over
+    # (the B-token prefill follows the hook, decode silently ignored it)
+    monkeypatch.setenv("KH_SHAPE_FFN", "1,4,512,256")
+    r = _ffi.plan_decode_ring(4096, 11008, 32000, True)
+    assert r["ffn13"]["slots"] == 0 and r["cls"]["slots"] == 2
+    monkeypatch.delenv("KH_SHAPE_FFN")
+    monkeypatch.setenv("KH_SHAPE_CLS", "1,4,512,256")
+    r = _ffi.plan_decode_ring(4096, 11008, 32000, True)
+    assert r["ffn13"]["slots"] == 2 and r["cls"]["slots"] == 0
+    monkeypatch.delenv("KH_SHAPE_CLS")
+    assert _ffi.plan_decode_ring(4096, 11008, 32000, True)["cls"]["slots"] == 2
     _ffi.sync_env()
     csrc = os.path.join(ROOT, "kuiperllama_amd", "csrc")
     for f in os.listdir(csrc):

@@ -65,3 +65,57 @@ def test_traffic_provenance_names_the_kernel_sources():
     assert src["collected_on_commit"] and src["kernel_sources_unchanged"] in (True, False)
     assert len(kernel_sources_sha1()) == 40
 
+
+
+def test_line_layout_carries_both_halves_of_the_metric_as_scalars():
+    """the driver's record keeps the contract's objects (`config`, `roofline`, `cpu_baseline`) with
+    their scalar members and only the NAMES of other top-level keys, so the Llama-2-7B int8 half of BASELINE's metric
+    and both whole-step fractions must sit inside those objects as scalars; contract scalars first, bulky sections
+    last, `summary` at the very end."""
+    import argparse
+    import json
+    from kuiperllama_amd import binfmt
+    bench = _bench()
+    spec = binfmt.PRESETS["llama3.2-1b"]
+    args = argparse.Namespace(steps=20, warmup=5)
+    roof = {"bound": "hbm", "kernel": "k_ffn13", "achieved": 6200.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.775,
+            "traffic": 1.345e8, "traffic_source": {"file": "x"}, "bytes_per_launch": 1.34e8, "avg_launch_us": 21.6,
+            "step": {"achieved": 5300.0, "frac": 0.6625, "bytes_per_token": 4.948e9}, "kernels_avg_us": {"ffn13": 21.6},
+            "kernels_sum_us_per_token": 916.0}
+    res = {"value": 1070.0, "ms_per_step": 0.9346, "roofline": roof, "replicas": {"n": 1}, "tok_s_128_steps": 1060.0,
+           "cpu_baseline": {"value": 33.0, "unit": "tokens/s", "cores": 16, "kind": "reference", "sample": "s",
+                            "host": {"nproc": 256}, "port": {"value": 20.0}}}
+    sroof = dict(roof, achieved=5700.0, frac=0.7125, step={"achieved": 4430.0, "frac": 0.55375, "bytes_per_token": 7.03e9})
+    secondary = {"config": {"workload": "llama2-7b-int8 greedy decode"}, "value": 630.0, "unit": "tokens/s",
+                 "ms_per_step": 1.587, "roofline": sroof, "tok_s_128_steps": 621.0}
+    line = bench.assemble_line(spec, args, 1, res, secondary, {"tinyllama-1.1b": {"value": 1090.0, "tokens_match": True}},
+                               [], "none")
+    keys = list(line)
+    # the contract's keys, in the contract's order, ahead of everything else
+    contract = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype"]
+    assert keys[:len(contract)] == contract
+    # small scalars before any object; the bulky sections behind the contract's objects; summary last
+    first_obj = next(i for i, k in enumerate(keys) if isinstance(line[k], (dict, list)))
+    for k in ("tok_s_128_steps", "secondary_value", "secondary_ms_per_step", "secondary_step_frac"):
+        assert keys.index(k) < first_obj and isinstance(line[k], float)
+    for k in ("secondary", "other_configs", "prefill", "runs"):
+        assert keys.index(k) > keys.index("cpu_baseline") > keys.index("roofline") > keys.index("config")
+    assert keys[-1] == "summary"
+    # what a parser that keeps only scalar members of the contract's objects still sees
+    r = {k: v for k, v in line["roofline"].items() if not isinstance(v, (dict, list))}
+    assert r["frac"] == 0.775 and r["step_frac"] == 0.6625 and r["step_achieved"] == 5300.0
+    assert r["secondary_frac"] == 0.7125 and r["secondary_step_frac"] == 0.55375
+    c = {k: v for k, v in line["config"].items() if not isinstance(v, (dict, list))}
+    assert c["secondary_workload"].startswith("llama2-7b-int8") and c["secondary_value"] == 630.0
+    assert c["secondary_tok_s_128_steps"] == 621.0 and c["tok_s_128_steps"] == 1060.0
+    # scalars of an object come before its nested members
+    rk = list(line["roofline"])
+    assert max(rk.index(k) for k in r) < min(rk.index(k) for k in ("traffic_source", "step", "kernels_avg_us"))
+    assert list(line["cpu_baseline"])[-2:] == ["host", "port"]
+    assert line["summary"]["secondary_value"] == 630.0 and line["north_star_floor"]["met"] is True
+    json.dumps(line)
+    # without a secondary workload (N > 1) the keys stay, as nulls
+    line = bench.assemble_line(spec, args, 2, res, None, None, ["load"], "nccl")
+    assert line["secondary_value"] is None and line["roofline"]["secondary_step_frac"] is None
+    assert "secondary" not in line and line["skipped_sections"] == ["load"] and list(line)[-1] == "summary"
