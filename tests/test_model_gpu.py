@@ -577,8 +577,12 @@ def test_real_stride_deep_positions_vs_oracle(gpu, oracle):
             if top2[1] - top2[0] > 2 * FULL_LOGIT_ATOL_F32:
                 assert nxt == int(np.argmax(lo)), (pos, mode)
             kg, vg = m.read_kv(2, pos, 1)
-            np.testing.assert_allclose(kg[0], krow, rtol=0, atol=5e-6, err_msg=f"K row {pos} {mode}")
-            np.testing.assert_allclose(vg[0], vrow, rtol=0, atol=5e-6, err_msg=f"V row {pos} {mode}")
+            # rows of the THIRD layer (|k| up to ~3): fp32 round-off of two layers of residual updates in front of
+            # them.  The fused kernels apply the RMS scale behind the dot product (rs * (W . (g * x)), kh_gemv.h),
+            # the oracle in front of it (W . (g * (rs * x)), cpu/rmsnorm_kernel.cpp:24-32): up to 5.5e-6 apart here
+            # (the unfused path, which keeps the oracle's order, stays below 5e-6)
+            np.testing.assert_allclose(kg[0], krow, rtol=0, atol=1e-5, err_msg=f"K row {pos} {mode}")
+            np.testing.assert_allclose(vg[0], vrow, rtol=0, atol=1e-5, err_msg=f"V row {pos} {mode}")
     print(f"real-stride deep positions: max |logit - oracle| {worst:.2e}")
     m.close()
 
