@@ -518,6 +518,14 @@ def measure(spec, args, rank, world, local_rank, primary):
         "words_head": words[:8],
         "replicas": replicas.spread(per),
     }
+    cfg = getattr(m, "cfg", None)  # kh_config: what the self-checks of kh_model_create_* decided for this model
+    out["selftests"] = {"ring": getattr(cfg, "ring_selftest", None), "attn_merge": getattr(cfg, "attn_merge_selftest", None),
+                        "legend": "0 n/a, 1 passed, -1 failed: fallback in use, 2 (attn_merge) fenced form requested"}
+    if hasattr(m, "kv_bytes"):
+        kv_res, kv_com = m.kv_bytes()
+        out["kv_cache"] = {"reserved_bytes": kv_res, "committed_bytes_after_timed_run": kv_com,
+                           "what": "address range of the reference's [layer, seq_len, kv_dim] x 2 allocation vs the HBM "
+                                   "mapped behind it after the timed run (8-MiB chunks, on demand)"}
     ref_words = words
     if args.extras:
         # SURVEY 8d extras, all outside the contract's timed region: repeated runs (median) and the
@@ -706,7 +714,13 @@ def assemble_line(spec, args, world, res, secondary, others, skipped, timing_bac
               "secondary_workload": summary["secondary_workload"],
               "secondary_value": summary["secondary_value"],
               "secondary_ms_per_step": summary["secondary_ms_per_step"],
-              "secondary_tok_s_128_steps": summary["secondary_tok_s_128_steps"]}
+              "secondary_tok_s_128_steps": summary["secondary_tok_s_128_steps"],
+              "kv_cache_committed_bytes": (res.get("kv_cache") or {}).get("committed_bytes_after_timed_run"),
+              "kv_cache_reserved_bytes": (res.get("kv_cache") or {}).get("reserved_bytes"),
+              "selftest_ring": res.get("selftests", {}).get("ring"),
+              "selftest_attn_merge": res.get("selftests", {}).get("attn_merge"),
+              "secondary_selftest_ring": (secondary.get("selftests") or {}).get("ring") if sec_ok else None,
+              "secondary_selftest_attn_merge": (secondary.get("selftests") or {}).get("attn_merge") if sec_ok else None}
     line = {
         "metric": "decode tokens/sec",
         "value": res["value"], "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
@@ -725,6 +739,9 @@ def assemble_line(spec, args, world, res, secondary, others, skipped, timing_bac
     if "cpu_baseline" in res:
         line["cpu_baseline"] = _flat_first(res["cpu_baseline"])
     line["replicas"] = res["replicas"]
+    if "kv_cache" in res:
+        line["kv_cache"] = res["kv_cache"]
+    line["selftests"] = res.get("selftests")
     line["runs"] = res.get("runs")
     line["tok_s_128_steps_is"] = res.get("tok_s_128_steps_is")
     line["latency_us_at_pos"] = res.get("latency_us_at_pos")
@@ -817,7 +834,7 @@ def main(argv=None):
                          "roofline": r2["roofline"], "runs": r2.get("runs"),
                          "tok_s_128_steps": r2.get("tok_s_128_steps"),
                          "latency_us_at_pos": r2.get("latency_us_at_pos"),
-                         "prefill": r2.get("prefill")}
+                         "prefill": r2.get("prefill"), "selftests": r2.get("selftests")}
             if "cpu_baseline" in r2:
                 secondary["cpu_baseline"] = r2["cpu_baseline"]
             if "max_logit_err_vs_oracle" in r2:

@@ -194,6 +194,16 @@ typedef struct kh_config {
   float rope_theta, rms_eps;
   int64_t weight_bytes; /* bytes of the weight arena resident in HBM */
   int32_t launches_per_token; /* 5 per layer + classifier + sampler */
+  /* Self-checks run once at the end of kh_model_create_* (csrc/kh_model_selftest.hip), about a millisecond:
+   *   ring_selftest        the int8 LDS-DMA ring kernels against the register-tile kernels of the same launches on
+   *                        this model's own weights: 0 = no ring kernel planned (fp32, geometry, KH_RING=0) or skipped,
+   *                        1 = outputs identical, -1 = mismatch: this model runs the register-tile kernels;
+   *   attn_merge_selftest  the fence-free in-launch merge of the decode-attention time splits against the fenced
+   *                        form: 0 = not applicable (no time splits in this cache) or skipped, 1 = identical,
+   *                        -1 = mismatch: this model uses the fenced form, 2 = the fenced form was requested
+   *                        (KH_FLAG_ATTN_MERGE_FENCED / KH_ATTN_FENCED=1).
+   * Hook KH_SELFTEST=0 skips both, KH_SELFTEST_FAIL="ring,attn" injects a failure (tests). */
+  int32_t ring_selftest, attn_merge_selftest;
 } kh_config;
 
 /* Model::read_model_file + init (model.cpp:41-123, llama3.cpp:107-145) */
@@ -229,6 +239,11 @@ int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t is_prompt,
 int kh_model_get_logits(kh_model* m, float* h_logits);
 /* device pointers of the KV cache [layer, cache_len, kv_dim] (tests) */
 int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache);
+/* bytes of the KV cache: *reserved = the address range of [layer, cache_len, kv_dim] floats x 2 (the reference's
+ * up-front allocation, llama3.cpp:469-472), *committed = HBM actually backing it now.  The range is reserved at
+ * creation and memory is mapped in 8-MiB chunks as generate / predict / prefill / kh_model_write_kv first reach
+ * rows (hook KH_KV_VMM=0: one plain allocation, committed == reserved).  kh_model_get_kv commits everything. */
+int kh_model_kv_bytes(const kh_model* m, int64_t* reserved, int64_t* committed);
 /* copy rows [row0, row0+nrows) of one layer's K and V cache to host (tests) */
 int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows, float* h_k,
                      float* h_v);

@@ -21,7 +21,7 @@ EXPORTS = [
     "kh_argmax_f32_host", "kh_softmax_f32", "kh_scale_f32", "kh_scale_sum_f32",
     "kh_model_create_from_file", "kh_model_create_from_host_image",
     "kh_model_create_from_device_weights", "kh_model_destroy", "kh_model_get_config",
-    "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_read_kv", "kh_model_write_kv",
+    "kh_model_stream", "kh_model_get_load_ms", "kh_model_predict", "kh_model_get_logits", "kh_model_get_kv", "kh_model_kv_bytes", "kh_model_read_kv", "kh_model_write_kv",
     "kh_spm_create_from_file", "kh_spm_create_from_memory", "kh_spm_destroy", "kh_spm_vocab_size",
     "kh_spm_bos_id", "kh_spm_eos_id", "kh_spm_unk_id", "kh_spm_encode", "kh_spm_decode",
     "kh_bpe_create_from_file", "kh_bpe_create_from_memory", "kh_bpe_destroy", "kh_bpe_vocab_size",
@@ -62,7 +62,8 @@ class Config(C.Structure):
         "dim", "hidden_dim", "layer_num", "head_num", "kv_head_num", "vocab_size", "seq_len",
         "kv_dim", "kv_mul", "head_size", "is_shared_weight", "is_quant", "group_size", "family",
         "rope_mode", "cache_len")] + [("rope_theta", C.c_float), ("rms_eps", C.c_float),
-                                      ("weight_bytes", C.c_int64), ("launches_per_token", C.c_int32)]
+                                      ("weight_bytes", C.c_int64), ("launches_per_token", C.c_int32),
+                                      ("ring_selftest", C.c_int32), ("attn_merge_selftest", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -123,6 +124,7 @@ def lib() -> C.CDLL:
     L.kh_model_predict.argtypes = [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32)]
     L.kh_model_get_logits.argtypes = [_vp, _vp]
     L.kh_model_get_kv.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp)]
+    L.kh_model_kv_bytes.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
     L.kh_model_read_kv.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp]
     L.kh_model_write_kv.argtypes = [_vp, _i32, _i32, _i32, _vp, _vp]
     L.kh_model_generate.argtypes = [_vp, C.POINTER(_i32), _i32, _i32, _i32, C.POINTER(_i32),
@@ -187,7 +189,7 @@ def debug_get(key: str) -> Optional[str]:
     return None if v is None else v.decode()
 
 
-_HOOK_PREFIXES = ("KH_SHAPE_", "KH_ATTN_", "KH_PG_", "KH_PREFILL", "KH_RING")
+_HOOK_PREFIXES = ("KH_SHAPE_", "KH_ATTN_", "KH_PG_", "KH_PREFILL", "KH_RING", "KH_SELFTEST", "KH_KV_")
 _ENV_MIRRORED = {}  # hook -> value, as last written into the table FROM os.environ by sync_env()
 _ENV_SEEDED = False
 

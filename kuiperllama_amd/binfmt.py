@@ -98,6 +98,20 @@ class ModelSpec:
         kvb = L * (2 * (pos + 1) * kv * 4 + 2 * kv * 4)
         return float(wbytes + small + kvb)
 
+    def kernel_bytes(self) -> Dict[str, float]:
+        """Algorithmic HBM bytes of ONE launch of each weight-streaming kernel of the decode step:
+        the rows of its matrices once (+ group scales), its input vector (+ norm weight) once, its output once."""
+        d, kv, h, v = self.dim, self.kv_dim, self.hidden_dim, self.vocab_size
+
+        def w(n):
+            return float(n + (n // self.group_size) * 4 if self.quant else n * 4)
+        bias = (d + 2 * kv) * 4 if self.has_bias else 0
+        return {"qkv": w((d + 2 * kv) * d) + 2 * d * 4 + (d + 2 * kv) * 4 + bias,
+                "wo": w(d * d) + d * 4 + 2 * d * 4,
+                "ffn13": w(2 * h * d) + 2 * d * 4 + h * 4,
+                "w2": w(d * h) + h * 4 + 2 * d * 4,
+                "cls": w(v * d) + 2 * d * 4 + v * 4}
+
 
 # BASELINE.json configs (SURVEY.md §8 table) -------------------------------------------------
 PRESETS: Dict[str, ModelSpec] = {

@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkuiper_hip.so")
-SOURCES = ["kh_ops.hip", "kh_model_load.hip", "kh_model_step.hip", "kh_model_prefill.hip", "kh_model_profile.hip",
+SOURCES = ["kh_ops.hip", "kh_model_load.hip", "kh_model_step.hip", "kh_model_prefill.hip", "kh_model_profile.hip", "kh_model_selftest.hip",
            "kh_tokenizer.cpp", "kh_bpe.cpp", "kh_debug.cpp"]
 HEADERS = ["kh_common.h", "kh_gemv.h", "kh_attn.h", "kh_fused.h", "kh_q8ring.h", "kh_fused_ring.h", "kh_prefill.h", "kh_gemm.h", "kh_pattn.h", "kh_unicode_tables.h",
            "kh_model_internal.h",

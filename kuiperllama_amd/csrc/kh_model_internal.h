@@ -68,6 +68,23 @@ struct kh_model {
   float* part_val = nullptr;
   int32_t* part_idx = nullptr;
   int nparts = 0;
+  // KV cache on reserved addresses, physical memory mapped on demand (kh_model_load.hip::kv_ensure): the contiguous
+  // [layer, cache_len, kv_dim] addressing of llama3.cpp:469-472 with HBM committed only for the rows a sequence reached
+  struct KvVmm {
+    bool on = false;
+    size_t chunk = 0;      // mapping unit in bytes (a multiple of the allocation granularity)
+    size_t reserved = 0;   // bytes reserved per cache (K and V each)
+    size_t mapped = 0;     // bytes mapped, K + V
+    std::vector<uint8_t> have[2];  // per chunk of the K / V reservation: mapped?
+    struct Run {
+      void* va;
+      size_t len;
+      hipMemGenericAllocationHandle_t h;
+    };
+    std::vector<Run> runs;
+    int rows_all = 0;      // rows [0, rows_all) of EVERY layer are mapped
+  };
+  KvVmm kv;
   float load_ms = 0.f;      // host image -> HBM upload time (kh_model_get_load_ms)
   std::thread unmap_thread;  // kh_model_create_from_file: munmap of the file off the critical path, joined by destroy
   void* attn_ws = nullptr;  // split-T attention partials + tickets (kh_attn.h)
@@ -170,6 +187,14 @@ void destroy_step_graphs(kh_model* m);
 int step_graph(kh_model* m, int n_forced, int variant, bool steps8, hipGraphExec_t* out);
 // the same for a graph of `nsteps` in {1, 2, 4, 8} steps (the tail of a run: 20 steps = 8 + 8 + 4)
 int step_graph_n(kh_model* m, int n_forced, int variant, int nsteps, hipGraphExec_t* out);
+// ---- kh_model_load.hip ----------------------------------------------------------------------
+// Make rows [0, rows) of the K / V cache usable before anything that touches them is enqueued: every layer, or one
+// (layer >= 0).  No-op for rows that are mapped already and for caches that are plainly allocated.  Newly mapped
+// memory is zeroed on the model's stream.
+int kv_ensure(kh_model* m, int rows, int layer = -1);
+// ---- kh_model_selftest.hip ------------------------------------------------------------------
+// ring kernels vs register tiles, fence-free vs fenced split merge: once at the end of kh_model_create_*
+int run_selftests(kh_model* m);
 // ---- kh_model_prefill.hip -------------------------------------------------------------------
 bool prefill_supported(const kh_model* m);  // B-token VALU path
 bool pg_supported(const kh_model* m);       // MFMA GEMM path

@@ -307,6 +307,147 @@ size_t expected_weight_bytes(const kh_config& c) {
   return q + (q / (size_t)c.group_size) * sizeof(float) + (V * dim + 2 * L * dim + dim) * sizeof(float);
 }
 
+// ---- KV cache: addresses reserved, HBM mapped on demand -------------------------------------------------------------
+// The reference allocates [layer_num, seq_len, kv_dim] floats for K and for V up front (llama3.cpp:469-472): 8.6 GB
+// for Llama-3.2-1B's 131072-row context, whatever the sequence length - and on some boxes of the pool that one
+// hipMalloc takes 0.3-0.5 s, more than the weight upload (profiles/r5_load_probe.txt box B).  Here the same contiguous
+// address range is RESERVED (hipMemAddressReserve: no memory, no time) and physical memory is mapped in chunks of
+// 8 MiB as generate / predict / prefill / kh_model_write_kv first reach rows (hipMemCreate + hipMemMap +
+// hipMemSetAccess on the host, before the launches that touch the rows are enqueued; the new memory is zeroed on the
+// model's stream).  Kernel addressing (model.cpp:226-243's slices) and captured graphs are unaffected: the base
+// pointers never change.  A 128-step run of Llama-3.2-1B commits 256 MiB of cache instead of 8.6 GB.
+// Hook KH_KV_VMM=0 (or a runtime without the virtual-memory API): one plain allocation, as before.
+static int kv_ensure_impl(kh_model* m, int row0, int rows, int layer);
+static void kv_release(kh_model* m);
+static int kv_allocate(kh_model* m) {
+  const kh_config& c = m->cfg;
+  const size_t total = (size_t)c.layer_num * (size_t)c.cache_len * c.kv_dim * sizeof(float);
+  kh_model::KvVmm& kv = m->kv;
+  if (!dbg_off("KH_KV_VMM")) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = m->opts.device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
+      size_t chunk = (size_t)8 << 20;  // ONE size for every mapping of every model in the process (see kv_ensure)
+      chunk = (chunk + gran - 1) / gran * gran;
+      const size_t reserved = (total + chunk - 1) / chunk * chunk;
+      void *pk = nullptr, *pv = nullptr;
+      if (hipMemAddressReserve(&pk, reserved, chunk, nullptr, 0) == hipSuccess) {
+        if (hipMemAddressReserve(&pv, reserved, chunk, nullptr, 0) == hipSuccess) {
+          kv.on = true;
+          kv.chunk = chunk;
+          kv.reserved = reserved;
+          kv.have[0].assign(reserved / chunk, 0);
+          kv.have[1].assign(reserved / chunk, 0);
+          m->kcache = (float*)pk;
+          m->vcache = (float*)pv;
+          // trial: the first row of layer 0 (every sequence needs it).  A process in which this fails - e.g. one whose
+          // other users of the API mapped other sizes, see kv_ensure - takes the plain allocation below instead of
+          // failing at its first generate
+          if (kv_ensure_impl(m, 0, 1, 0) == KH_OK) return KH_OK;
+          kv_release(m);
+          kv = kh_model::KvVmm();
+        } else {
+          (void)hipMemAddressFree(pk, reserved);
+        }
+      }
+    }
+    (void)hipGetLastError();  // no virtual-memory API on this runtime / device: plain allocation
+  }
+  int rc;
+  if ((rc = dalloc(&m->kcache, total / sizeof(float))) != KH_OK) return rc;
+  return dalloc(&m->vcache, total / sizeof(float));
+}
+static void kv_release(kh_model* m) {
+  kh_model::KvVmm& kv = m->kv;
+  if (!kv.on) {
+    if (m->kcache) (void)hipFree(m->kcache);
+    if (m->vcache) (void)hipFree(m->vcache);
+  } else {
+    for (const auto& r : kv.runs) {
+      (void)hipMemUnmap(r.va, r.len);
+      (void)hipMemRelease(r.h);
+    }
+    kv.runs.clear();
+    if (m->kcache) (void)hipMemAddressFree(m->kcache, kv.reserved);
+    if (m->vcache) (void)hipMemAddressFree(m->vcache, kv.reserved);
+    kv.on = false;
+  }
+  m->kcache = m->vcache = nullptr;
+}
+// rows [row0, rows) of one layer (layer >= 0) or of every layer
+static int kv_ensure_impl(kh_model* m, int row0, int rows, int layer) {
+  kh_model::KvVmm& kv = m->kv;
+  if (!kv.on || rows <= 0) return KH_OK;
+  const kh_config& c = m->cfg;
+  if (rows > c.cache_len) rows = c.cache_len;
+  if (rows <= kv.rows_all || row0 >= rows) return KH_OK;
+  if (row0 < 0) row0 = 0;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = m->opts.device;
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  const size_t row_b = (size_t)c.kv_dim * sizeof(float), layer_b = (size_t)c.cache_len * row_b;
+  const int l0 = layer >= 0 ? layer : 0, l1 = layer >= 0 ? layer + 1 : c.layer_num;
+  for (int which = 0; which < 2; ++which) {
+    char* base = (char*)(which ? m->vcache : m->kcache);
+    std::vector<uint8_t>& have = kv.have[which];
+    for (int l = l0; l < l1; ++l) {
+      // bytes [b0, b1) of the reservation must be mapped
+      const size_t b0 = (size_t)l * layer_b + (size_t)row0 * row_b, b1 = (size_t)l * layer_b + (size_t)rows * row_b;
+      size_t ch = b0 / kv.chunk;
+      const size_t ch_end = (b1 + kv.chunk - 1) / kv.chunk;
+      while (ch < ch_end) {
+        if (have[ch]) {
+          ++ch;
+          continue;
+        }
+        size_t e = ch;
+        while (e < ch_end && !have[e]) ++e;  // a run of unmapped chunks: zeroed with one memset
+        // ONE handle per chunk, every handle the same size: on this runtime (ROCm 7.2) hipMemSetAccess returns
+        // "invalid argument" for a mapping that is smaller than one made earlier in the same process
+        // (tools/mb_vmm2.hip, profiles/r6_mb_vmm.txt); equal-sized mappings - what PyTorch's expandable segments
+        // use - are reliable, and a chunk costs 13 us to create + map + enable
+        for (size_t k = ch; k < e; ++k) {
+          kh_model::KvVmm::Run r;
+          r.va = base + k * kv.chunk;
+          r.len = kv.chunk;
+          const char* what = "hipMemCreate";
+          hipError_t err = hipMemCreate(&r.h, r.len, &prop, 0);
+          if (err == hipSuccess) {
+            what = "hipMemMap";
+            err = hipMemMap(r.va, r.len, 0, r.h, 0);
+            if (err == hipSuccess) {
+              what = "hipMemSetAccess";
+              err = hipMemSetAccess(r.va, r.len, &acc, 1);
+              if (err != hipSuccess) (void)hipMemUnmap(r.va, r.len);
+            }
+            if (err != hipSuccess) (void)hipMemRelease(r.h);
+          }
+          if (err != hipSuccess) {
+            fprintf(stderr, "[kh] KV cache: %s of %zu MiB at chunk %zu of the %s cache (layer %d) failed: %s\n", what,
+                    r.len >> 20, k, which ? "V" : "K", l, hipGetErrorString(err));
+            (void)hipGetLastError();
+            return (int)err;
+          }
+          kv.runs.push_back(r);
+          have[k] = 1;
+          kv.mapped += r.len;
+        }
+        KH_CHECK_HIP(hipMemsetAsync(base + ch * kv.chunk, 0, (e - ch) * kv.chunk, m->stream));
+        ch = e;
+      }
+    }
+  }
+  if (layer < 0 && row0 == 0) kv.rows_all = rows;
+  return KH_OK;
+}
+
 int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   const kh_config& c = m->cfg;
   int rc;
@@ -326,8 +467,7 @@ int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   KH_ALLOC(m->logits, (size_t)c.vocab_size);
   KH_ALLOC(m->score, (size_t)c.head_num * CL);
   pc.lap("weight table + small buffers");
-  KH_ALLOC(m->kcache, (size_t)c.layer_num * CL * c.kv_dim);
-  KH_ALLOC(m->vcache, (size_t)c.layer_num * CL * c.kv_dim);
+  if ((rc = kv_allocate(m)) != KH_OK) return rc;
   KH_ALLOC(m->sin_cache, CL * c.head_size);
   KH_ALLOC(m->cos_cache, CL * c.head_size);
   KH_ALLOC(m->d_pos, 1);
@@ -385,8 +525,10 @@ int finish_create(kh_model* m, SinCosJob* sincos = nullptr) {
   KH_ALLOC(m->part_idx, (size_t)m->nparts);
 #undef KH_ALLOC
   pc.lap("caches, tables, plans, workspace");
-  KH_CHECK_HIP(hipMemsetAsync(m->kcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
-  KH_CHECK_HIP(hipMemsetAsync(m->vcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
+  if (!m->kv.on) {  // a mapped-on-demand cache zeroes what it maps (kv_ensure)
+    KH_CHECK_HIP(hipMemsetAsync(m->kcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
+    KH_CHECK_HIP(hipMemsetAsync(m->vcache, 0, sizeof(float) * c.layer_num * CL * c.kv_dim, m->stream));
+  }
   KH_CHECK_HIP(hipMemsetAsync(m->d_pos, 0, sizeof(int32_t), m->stream));
   KH_CHECK_HIP(hipMemsetAsync(m->d_token, 0, sizeof(int32_t), m->stream));
   // sin/cos table: computed on the host with libm exactly as the CPU backend does
@@ -443,6 +585,10 @@ int new_model(const int32_t* h_header, const kh_model_opts* opts, kh_model** out
 
 }  // namespace
 
+namespace khm {
+int kv_ensure(kh_model* m, int rows, int layer) { return kv_ensure_impl(m, 0, rows, layer); }
+}  // namespace khm
+
 // =============================================================================================
 extern "C" void kh_model_destroy(kh_model* m) {
   if (!m) return;
@@ -461,11 +607,12 @@ extern "C" void kh_model_destroy(kh_model* m) {
   if (m->h_forced_pin) (void)hipHostFree(m->h_forced_pin);
   if (m->first_logits) (void)hipFree(m->first_logits);
   void* bufs[] = {m->x,      m->rms,    m->q,         m->att,       m->h1,       m->h3,
-                  m->w2o,    m->logits, m->score,     m->kcache,    m->vcache,   m->sin_cache,
+                  m->w2o,    m->logits, m->score,     m->sin_cache,
                   m->cos_cache, m->part_val, m->part_idx, m->d_pos, m->d_token,  m->d_next,
                   m->d_forced, m->d_words, m->attn_ws};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  kv_release(m);
   if (m->owns_arena && m->arena) (void)hipFree(m->arena);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
@@ -487,6 +634,7 @@ static int create_from_device_weights_impl(const int32_t* h_header, const void* 
   m->arena_bytes = weight_nbytes;
   m->cfg.weight_bytes = (int64_t)expected_weight_bytes(m->cfg);
   rc = finish_create(m);
+  if (rc == KH_OK) rc = run_selftests(m);  // the weights are resident: ring kernels / split merge against their fallbacks
   if (rc != KH_OK) {
     kh_model_destroy(m);
     m = nullptr;
@@ -562,6 +710,8 @@ static int create_from_host_image_impl(const void* h_image, size_t nbytes, const
     if (es != hipSuccess) rc = (int)es;
   }
   pc.lap("upload || buffers, joined");
+  if (rc == KH_OK) rc = run_selftests(m);
+  pc.lap("self-tests");
   if (rc != KH_OK) {
     kh_model_destroy(m);
     m = nullptr;
@@ -672,8 +822,20 @@ extern "C" int kh_model_first_sample(kh_model* m, kh_first_sample* out) {
 }
 extern "C" int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache) {
   if (!m || !d_kcache || !d_vcache) return KH_ERR_INVALID_ARG;
+  // raw pointers leave the library: every row must be backed (a mapped-on-demand cache commits all of it here)
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  const int rc = kv_ensure(m, m->cfg.cache_len);
+  if (rc != KH_OK) return rc;
   *d_kcache = m->kcache;
   *d_vcache = m->vcache;
+  return KH_OK;
+}
+
+extern "C" int kh_model_kv_bytes(const kh_model* m, int64_t* reserved, int64_t* committed) {
+  if (!m || !reserved || !committed) return KH_ERR_INVALID_ARG;
+  const int64_t total = 2 * (int64_t)m->cfg.layer_num * m->cfg.cache_len * m->cfg.kv_dim * (int64_t)sizeof(float);
+  *reserved = total;
+  *committed = m->kv.on ? (int64_t)m->kv.mapped : total;
   return KH_OK;
 }
 
@@ -682,6 +844,11 @@ extern "C" int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_
   if (!m || !h_k || !h_v || layer < 0 || layer >= m->cfg.layer_num || row0 < 0 || nrows <= 0 ||
       (int64_t)row0 + nrows > m->cfg.cache_len)
     return KH_ERR_INVALID_ARG;
+  KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  {
+    const int rc = kv_ensure_impl(m, row0, row0 + nrows, layer);  // rows nobody reached yet read as zeros
+    if (rc != KH_OK) return rc;
+  }
   const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
   const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
   KH_CHECK_HIP(hipMemcpyAsync(h_k, m->kcache + off, nb, hipMemcpyDeviceToHost, m->stream));
@@ -696,6 +863,10 @@ extern "C" int kh_model_write_kv(kh_model* m, int32_t layer, int32_t row0, int32
       (int64_t)row0 + nrows > m->cfg.cache_len)
     return KH_ERR_INVALID_ARG;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  {
+    const int rc = kv_ensure_impl(m, row0, row0 + nrows, layer);  // only the chunks these rows live in
+    if (rc != KH_OK) return rc;
+  }
   const size_t off = ((size_t)layer * m->cfg.cache_len + row0) * m->cfg.kv_dim;
   const size_t nb = (size_t)nrows * m->cfg.kv_dim * sizeof(float);
   // hipMemcpyDefault: the source may be host memory or memory of this device (unified addressing)

@@ -531,6 +531,7 @@ extern "C" int kh_model_prefill_gemm(kh_model* m, const int32_t* h_tokens, int32
   if (!pg_supported(m)) return KH_ERR_UNSUPPORTED;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
   int rc;
+  if ((rc = kv_ensure(m, pos0 + n)) != KH_OK) return rc;
   if ((rc = ensure_pg_buffers(m)) != KH_OK) return rc;
   if ((rc = ensure_pg_ws(m)) != KH_OK) return rc;
   m->pg_launch_failed = false;
@@ -578,6 +579,7 @@ extern "C" int kh_model_prefill(kh_model* m, const int32_t* h_tokens, int32_t n,
   if (!prefill_supported(m)) return KH_ERR_UNSUPPORTED;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
   int rc;
+  if ((rc = kv_ensure(m, pos0 + n)) != KH_OK) return rc;
   if ((rc = ensure_prefill_buffers(m)) != KH_OK) return rc;
   const int B = prefill_batch(m);
   for (int t0 = 0; t0 < n; t0 += B)
@@ -598,6 +600,7 @@ extern "C" int kh_model_time_prefill(kh_model* m, const int32_t* h_tokens, int32
     if (h_tokens[i] < 0 || h_tokens[i] >= c.vocab_size) return KH_ERR_RANGE;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
   int rc;
+  if ((rc = kv_ensure(m, pos0 + n + 1)) != KH_OK) return rc;
   if (mode == KH_PREFILL_TOKEN) {
     if ((rc = ensure_seq_cap(m, pos0 + n + 1)) != KH_OK) return rc;
     std::vector<int32_t> forced((size_t)m->seq_cap + 1, -1);

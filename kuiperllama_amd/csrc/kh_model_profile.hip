@@ -13,6 +13,10 @@ extern "C" int kh_model_profile_kernel(kh_model* m, int32_t kclass, int32_t pos,
   const kh_config& c = m->cfg;
   if (pos < 0 || pos >= c.cache_len) return KH_ERR_RANGE;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  {
+    const int rc = kv_ensure(m, pos + 1);
+    if (rc != KH_OK) return rc;
+  }
   set_state(m, 1 % c.vocab_size, pos);
   m->step_var = step_variant(m, pos, pos);  // the attention / wo pair a step at `pos` launches
   const bool per_layer = kclass < KH_K_CLS;
@@ -65,6 +69,7 @@ extern "C" int kh_model_time_step(kh_model* m, int32_t pos, int32_t reps, float*
   // deep positions (long-context probes): grow the forced/words buffers to cover `pos` and
   // (re)capture the step graph if that replaced them
   int rc;
+  if ((rc = kv_ensure(m, pos + 1)) != KH_OK) return rc;
   if ((rc = ensure_seq_cap(m, pos + 1)) != KH_OK) return rc;
   hipGraphExec_t ge = nullptr;
   if ((rc = step_graph(m, m->seq_cap + 1, step_variant(m, pos, pos), false, &ge)) != KH_OK) return rc;
@@ -93,6 +98,10 @@ extern "C" int kh_model_profile_step(kh_model* m, int32_t start_pos, int32_t n_s
   const kh_config& c = m->cfg;
   if (start_pos + n_steps > c.cache_len) return KH_ERR_RANGE;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  {
+    const int rc = kv_ensure(m, start_pos + n_steps);
+    if (rc != KH_OK) return rc;
+  }
   const int L = c.layer_num;
   const int nk = 5 * L + 2;
   std::vector<hipEvent_t> ev((size_t)nk + 1);

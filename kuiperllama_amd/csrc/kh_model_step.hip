@@ -644,8 +644,9 @@ extern "C" int kh_model_predict(kh_model* m, int32_t token, int32_t pos, int32_t
   const kh_config& c = m->cfg;
   if (token < 0 || token >= c.vocab_size || pos < 0 || pos >= c.cache_len) return KH_ERR_RANGE;
   KH_CHECK_HIP(hipSetDevice(m->opts.device));
+  int rc = kv_ensure(m, pos + 1);  // cache rows 0 .. pos backed by HBM before the step is enqueued
+  if (rc != KH_OK) return rc;
   set_state(m, token, pos);  // embedding() + fill_input (llama3.cpp:578-598, model.cpp:245-263)
-  int rc = KH_OK;
   if (exec == KH_EXEC_UNFUSED) {
     rc = launch_step_unfused(m, pos);
   } else if (exec == KH_EXEC_FUSED || exec == KH_EXEC_GRAPH) {
@@ -716,6 +717,9 @@ extern "C" int kh_model_generate_until(kh_model* m, const int32_t* h_prompt, int
   if (exec != KH_EXEC_GRAPH && exec != KH_EXEC_FUSED) return KH_ERR_INVALID_ARG;
 
   if ((rc = ensure_seq_cap(m, total_steps)) != KH_OK) return rc;
+  // every cache row this call can reach is backed by HBM before its first launch (the dry launches of fresh graphs
+  // below touch rows 0 .. 7); mapping happens here, on the host, outside the event bracket of the step loop
+  if ((rc = kv_ensure(m, total_steps < KH_GRAPH_STEPS ? KH_GRAPH_STEPS : total_steps)) != KH_OK) return rc;
   // pinned mirror of the words, sized like the device buffers so that a longer run later does not re-allocate it (a
   // hipHostMalloc inside the step loop's event bracket stalled the first 20-step run behind a 5-step one by 0.3 ms)
   if ((rc = ensure_pinned_words(m, m->seq_cap)) != KH_OK) return rc;

@@ -111,6 +111,13 @@ class KuiperModel:
         _ffi.check(_ffi.lib().kh_model_get_logits(self._h, out.ctypes.data), "kh_model_get_logits")
         return out
 
+    def kv_bytes(self) -> Tuple[int, int]:
+        """(reserved, committed) bytes of the KV cache: the address range of the reference's up-front allocation and
+        the HBM backing it right now (mapped on demand, kh_model_kv_bytes)."""
+        r, c = C.c_int64(0), C.c_int64(0)
+        _ffi.check(_ffi.lib().kh_model_kv_bytes(self._h, C.byref(r), C.byref(c)), "kh_model_kv_bytes")
+        return int(r.value), int(c.value)
+
     def kv_cache_ptrs(self) -> Tuple[int, int]:
         k, v = C.c_void_p(), C.c_void_p()
         _ffi.check(_ffi.lib().kh_model_get_kv(self._h, C.byref(k), C.byref(v)), "kh_model_get_kv")

@@ -319,6 +319,123 @@ def test_int8_ring_kernels_equal_register_tile_kernels(gpu, oracle, monkeypatch,
     m_reg.close()
 
 
+def test_create_time_selftests_and_their_fallbacks(gpu, oracle, monkeypatch):
+    """kh_model_create_* checks the two fast paths that are correct by test rather than by construction against
+    their fallbacks on the model's own device and weights (csrc/kh_model_selftest.hip): the int8 LDS-DMA ring kernels
+    vs the register-tile kernels, the fence-free in-launch merge of the attention time splits vs the fenced form.
+    kh_config reports both.  With a failure INJECTED (hook KH_SELFTEST_FAIL) the fallbacks must engage - ring off,
+    fenced merge on - and decode must still match the oracle token for token across the first split transitions;
+    KH_SELFTEST=0 skips the checks; a model asked for the fenced form reports 2.  The cache rows the attention check
+    borrowed are zero again afterwards."""
+    from kuiperllama_amd import _ffi
+    from kuiperllama_amd.model import KuiperModel
+    # int8, GQA (kv_mul 2), head size 64, a 1024-row cache: ring planned, four time splits at position 1023
+    spec = binfmt.ModelSpec(512, 1408, 2, 8, 4, 640, 1024, False, binfmt.FAMILY_LLAMA, True, 64,
+                            binfmt.ROPE_HALF, 500000.0, 1e-5, "selftest-int8")
+    img_d, img_h = _synth(spec, 77, gpu, wander=True)
+    assert _ffi.plan_decode_ring(spec.dim, spec.hidden_dim, spec.vocab_size, True, 64)["ffn13"]["slots"] == 2
+    want = oracle.OracleModel.from_spec(img_h, spec).generate([1, 7], 300)
+
+    m = KuiperModel.from_device_image(img_d, spec, flags=_ffi.KH_FLAG_ATTN_MERGE_IN_LAUNCH)
+    assert m.cfg.ring_selftest == 1 and m.cfg.attn_merge_selftest == 1
+    k0, v0 = m.read_kv(0, 0, 1024)
+    assert not k0.any() and not v0.any()
+    got, _ = m.generate([1, 7], 300, exec="graph")
+    assert got == want
+    ref_logits = m.logits()
+    m.close()
+
+    monkeypatch.setenv("KH_SELFTEST_FAIL", "ring,attn")
+    mf = KuiperModel.from_device_image(img_d, spec, flags=_ffi.KH_FLAG_ATTN_MERGE_IN_LAUNCH)
+    monkeypatch.delenv("KH_SELFTEST_FAIL")
+    assert mf.cfg.ring_selftest == -1 and mf.cfg.attn_merge_selftest == -1
+    got, _ = mf.generate([1, 7], 300, exec="graph")
+    assert got == want
+    # the fallbacks compute the same bits: register tiles == ring (by design), fenced == fence-free merge
+    assert np.array_equal(mf.logits(), ref_logits)
+    mf.close()
+
+    monkeypatch.setenv("KH_SELFTEST_FAIL", "attn")
+    ma = KuiperModel.from_device_image(img_d, spec)
+    monkeypatch.delenv("KH_SELFTEST_FAIL")
+    assert ma.cfg.ring_selftest == 1 and ma.cfg.attn_merge_selftest == -1
+    ma.close()
+
+    monkeypatch.setenv("KH_SELFTEST", "0")
+    ms = KuiperModel.from_device_image(img_d, spec)
+    monkeypatch.delenv("KH_SELFTEST")
+    assert ms.cfg.ring_selftest == 0 and ms.cfg.attn_merge_selftest == 0
+    ms.close()
+
+    mq = KuiperModel.from_device_image(img_d, spec, flags=_ffi.KH_FLAG_ATTN_MERGE_FENCED)
+    assert mq.cfg.ring_selftest == 1 and mq.cfg.attn_merge_selftest == 2
+    mq.close()
+    _ffi.sync_env()
+
+    # fp32 with a short cache: neither check applies
+    small = binfmt.ModelSpec(256, 704, 2, 4, 4, 300, 128, True, binfmt.FAMILY_LLAMA, False, 64,
+                             binfmt.ROPE_HALF, 500000.0, 1e-5, "selftest-small")
+    sd, _ = _synth(small, 3, gpu)
+    m0 = KuiperModel.from_device_image(sd, small)
+    assert m0.cfg.ring_selftest == 0 and m0.cfg.attn_merge_selftest == 0
+    m0.close()
+
+
+def test_kv_cache_is_reserved_and_mapped_on_demand(gpu, oracle, monkeypatch):
+    """The KV cache keeps the reference's contiguous [layer, cache_len, kv_dim] addressing (llama3.cpp:469-472,
+    model.cpp:226-243) but only its ADDRESS RANGE exists at creation; HBM is mapped in 8-MiB chunks as generate /
+    predict / prefill / write_kv first reach rows (kh_model_load.hip::kv_ensure).  Llama-3.2-1B's per-layer geometry
+    with the full 131072-row cache and 3 layers: 1.6 GB reserved; a 128-step run commits one chunk per layer and
+    cache, its tokens and logits equal the oracle's and those of a plainly allocated cache (KH_KV_VMM=0); rows nobody
+    reached read as zeros; rows written deep in the cache are there; graph replay across a chunk boundary works."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.ModelSpec(2048, 8192, 3, 32, 8, 4096, 131072, True, binfmt.FAMILY_LLAMA, False, 64,
+                            binfmt.ROPE_HALF, 500000.0, 1e-5, "kv-vmm-3layer")
+    img_d, img_h = _synth(spec, 17, gpu, wander=True)
+    MiB = 1 << 20
+    m = KuiperModel.from_device_image(img_d, spec)
+    reserved, committed0 = m.kv_bytes()
+    assert reserved == 2 * 3 * 131072 * 512 * 4
+    # creation commits at most what the attention self-check borrowed in layer 0 (4352 rows = 2 chunks per cache)
+    assert committed0 <= 4 * 8 * MiB
+    want = oracle.OracleModel.from_spec(img_h, spec).generate([1, 7], 128)
+    got, _ = m.generate([1, 7], 128, exec="graph")
+    assert got == want
+    lg = m.logits()
+    _, committed1 = m.kv_bytes()
+    assert committed0 <= committed1 <= committed0 + 2 * 3 * 8 * MiB  # one 8-MiB chunk (4096 rows) per layer and cache
+    k, v = m.read_kv(2, 5000, 4)  # never reached: zeros (and now mapped)
+    assert not k.any() and not v.any()
+    # a run that crosses the 4096-row chunk boundary under graph replay: rows 4090 .. 4103 land in two chunks
+    rng = np.random.default_rng(3)
+    for l in range(3):
+        kr = rng.standard_normal((4090, 512), dtype=np.float32)
+        m.write_kv(l, 0, kr, kr[::-1].copy())
+    t = m.time_step(4095, 3)
+    assert len(t) == 3 and all(x > 0 for x in t)
+    krow, _ = m.read_kv(1, 4095, 1)
+    assert np.isfinite(krow).all() and krow.any()  # the step wrote its K row into the second chunk
+    # deep rows
+    kr = rng.standard_normal((8, 512), dtype=np.float32)
+    m.write_kv(2, 131064, kr, 2 * kr)
+    k, v = m.read_kv(2, 131064, 8)
+    assert np.array_equal(k, kr) and np.array_equal(v, 2 * kr)
+    _, committed2 = m.kv_bytes()
+    assert committed2 < reserved // 4
+    m.close()
+
+    monkeypatch.setenv("KH_KV_VMM", "0")
+    mp = KuiperModel.from_device_image(img_d, spec)
+    monkeypatch.delenv("KH_KV_VMM")
+    r2, c2 = mp.kv_bytes()
+    assert r2 == reserved and c2 == reserved
+    got2, _ = mp.generate([1, 7], 128, exec="graph")
+    assert got2 == want and np.array_equal(mp.logits(), lg)
+    mp.close()
+    from kuiperllama_amd import _ffi
+    _ffi.sync_env()
+
+
 def test_loader_entry_points_agree(gpu):
     from kuiperllama_amd.model import KuiperModel
     spec, img, toks, ref = load_golden("ref_llama_mha_untied")

@@ -12,7 +12,11 @@
 //               [--theta 10000] [--eps 1e-5] [--steps 128] [--prompt 1,263] [--stop 2]
 //               [--exec graph|fused|unfused] [--max-seq-len N] [--device 0]
 //               [--tokenizer tokenizer.model | --tokenizer-json tokenizer.json [--hf-spaces]] [--text "a"]
+//               [--exact-prefill] [--fenced-merge]
 //
+// --exact-prefill = KH_FLAG_PREFILL_EXACT: the prompt phase bit for bit the reference's one-token-per-pass prompt
+// phase (demo/main.cpp:20-22); without it prompts of 17+ tokens run as fp32-MFMA GEMMs (tolerance parity, 8-10 x the
+// prompt tokens/s).  --fenced-merge = KH_FLAG_ATTN_MERGE_FENCED.  The self-checks of kh_model_create_* are printed.
 // Prints the generated ids and "steps/s" like demo/main.cpp:70-72.
 #include <chrono>
 #include <cstdio>
@@ -28,7 +32,7 @@ static void usage() {
                "usage: kuiper_demo model.bin [--family llama|qwen2] [--quant] [--rope interleaved|half]\n"
                "       [--theta F] [--eps F] [--steps N] [--prompt id,id,...] [--stop id,id] [--exec graph|fused|unfused]\n"
                "       [--max-seq-len N] [--device D] [--tokenizer tokenizer.model | --tokenizer-json tokenizer.json\n"
-               "       [--hf-spaces]] [--text \"...\"]\n");
+               "       [--hf-spaces]] [--text \"...\"] [--exact-prefill] [--fenced-merge]\n");
 }
 
 int main(int argc, char** argv) {
@@ -64,6 +68,8 @@ int main(int argc, char** argv) {
     else if (a == "--tokenizer") tok_path = next();
     else if (a == "--tokenizer-json") bpe_path = next();
     else if (a == "--hf-spaces") bpe_flags = 0;
+    else if (a == "--exact-prefill") o.flags |= KH_FLAG_PREFILL_EXACT;
+    else if (a == "--fenced-merge") o.flags |= KH_FLAG_ATTN_MERGE_FENCED;
     else if (a == "--text") {
       text = next();
       have_text = true;
@@ -151,6 +157,10 @@ int main(int argc, char** argv) {
                c.is_quant ? " int8" : "");
   std::fprintf(stderr, "weights: %.2f GB uploaded in %.1f ms (%.1f GB/s)\n", c.weight_bytes / 1e9,
                kh_model_get_load_ms(m), c.weight_bytes / 1e6 / (kh_model_get_load_ms(m) + 1e-9));
+  // kh_config: 0 n/a, 1 passed, -1 failed -> fallback in use, 2 (merge) fenced form requested
+  std::fprintf(stderr, "self-checks: int8 ring kernels %d, attention split merge %d; prompt phase: %s\n", c.ring_selftest,
+               c.attn_merge_selftest, (o.flags & KH_FLAG_PREFILL_EXACT) ? "exact (bit-identical to token-by-token)"
+                                                                        : "GEMM for 17+ tokens (fp32 round-off)");
   std::vector<int32_t> words((size_t)steps);
   int32_t n = 0;
   float gpu_ms = 0.f;

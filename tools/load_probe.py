@@ -30,12 +30,18 @@ try:
         m = KuiperModel.from_file(path, spec)
         wall = time.perf_counter() - t0
         up = m.load_ms
+        kv0 = m.kv_bytes()
+        t1 = time.perf_counter()
         words, _ = m.generate([1, 263], 8)
+        first_gen_ms = (time.perf_counter() - t1) * 1e3  # includes mapping the first KV chunks + graph capture
+        kv1 = m.kv_bytes()
         m.close()
         print(json.dumps({"load": i + 1, "after": "a 3-s pause" if i == 3 else ("the image's hipFree" if i == 0 else "the previous model's hipFree"),
                           "workload": name, "GB": round(n / 1e9, 2), "create_ms": round(wall * 1e3, 1),
                           "GB/s": round(n / wall / 1e9, 1), "upload_ms": round(up, 1),
                           "upload_GB/s": round(n / up / 1e6, 1), "other_ms": round(wall * 1e3 - up, 1),
+                          "kv_reserved_GB": round(kv0[0] / 1e9, 2), "kv_committed_MB_after_create": round(kv0[1] / 1e6, 1),
+                          "kv_committed_MB_after_8_steps": round(kv1[1] / 1e6, 1), "first_generate_ms": round(first_gen_ms, 1),
                           "words": words[:4]}), flush=True)
 finally:
     os.unlink(path)

@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--workload", default="llama3.2-1b")
     ap.add_argument("--commit", default=os.environ.get("KH_COMMIT", ""),
                     help="commit the counters were collected on (stamped into pmc_traffic.json)")
-    ap.add_argument("--command", default="tools/profile_round5.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
+    ap.add_argument("--command", default="tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE "
                                          "--kernel-trace -- python tools/pmc_workload.py <workload> --steps 8")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
