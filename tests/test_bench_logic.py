@@ -119,3 +119,29 @@ def test_line_layout_carries_both_halves_of_the_metric_as_scalars():
     line = bench.assemble_line(spec, args, 2, res, None, None, ["load"], "nccl")
     assert line["secondary_value"] is None and line["roofline"]["secondary_step_frac"] is None
     assert "secondary" not in line and line["skipped_sections"] == ["load"] and list(line)[-1] == "summary"
+
+
+def test_profiles_readme_tables_are_generated_from_the_profile_files():
+    """profiles/README.md quoted microseconds by hand and they drifted from the CSV they came
+    from.  The per-round kernel tables are now written by tools/profiles_readme.py from <round>_kernel_stats.csv,
+    <round>_pmc_<workload>.csv and the bench JSONs; this test regenerates them and requires README.md to hold
+    exactly that text, so a re-collected profile without a regenerated README (or a hand edit) fails here."""
+    spec = importlib.util.spec_from_file_location("profiles_readme", os.path.join(ROOT, "tools", "profiles_readme.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    readme = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    for rnd in ("r5", "r6"):
+        b = gen.block(rnd)
+        assert b in readme, f"profiles/README.md is stale for {rnd}: run `python tools/profiles_readme.py --round {rnd} --write`"
+        rows = [ln for ln in b.split("\n") if ln.startswith("| llama")]
+        assert len(rows) == 10  # five weight-streaming kernels of each metric workload
+        for ln in rows:
+            cells = [c.strip() for c in ln.strip("|").split("|")]
+            frac, ratio = float(cells[6]), cells[7]
+            assert 0.3 < frac < 0.9
+            assert ratio == "—" or 0.99 < float(ratio) < 1.05  # nothing is read twice from HBM
+    # the classifier keeps kernels of the metric workloads apart by instantiation, wo / w2 by workgroup width
+    assert gen.classify("k_gemv_res<true, 2, 6, 2>", 512) == ("llama2-7b-int8", "w2")
+    assert gen.classify("k_gemv_res<false, 4, 2, 2>", 256) == ("llama3.2-1b", "wo")
+    assert gen.classify("k_ffn13_ring<2, 4, false, StagerAsm<true, 4, 0> >", 256) == ("llama2-7b-int8", "ffn13")
+    assert gen.classify("k_pf_ffn13<true, 4>", 256) is None

@@ -47,15 +47,25 @@ def block(rnd: str) -> str:
             c = classify(r["kernel"], int(r["wg"]))
             if c and int(r["calls"]) >= 1000:  # the decode launches of the two metric workloads (prefill twins: k_pf_*)
                 rows.append((c, r))
-    try:
-        traffic = json.load(open(os.path.join(prof, "pmc_traffic.json")))
-    except OSError:
-        traffic = {}
-    tkey = {"wo": "gemv_res", "w2": "gemv_res"}
+    # HBM traffic per launch of every kernel INSTANTIATION from the round's own counter passes
+    # (<round>_pmc_<workload>.csv: FETCH_SIZE / WRITE_SIZE in KiB; read side x2 = the gfx950 half-count correction of
+    # a 16 B/lane stream, MI355X_MICROARCH.md HBM section - the same formula as pmc_traffic.json)
+    traffic = {}
+    for wl in ("llama3.2-1b", "llama2-7b-int8"):
+        try:
+            with open(os.path.join(prof, f"{rnd}_pmc_{wl}.csv")) as f:
+                acc = {}
+                for r in csv.DictReader(f):
+                    acc.setdefault(r["kernel"], {})[r["counter"]] = float(r["avg_kib"])
+            for k, v in acc.items():
+                if "FETCH_SIZE" in v:
+                    traffic[(wl, k)] = v["FETCH_SIZE"] * 1024 * 2 + v.get("WRITE_SIZE", 0.0) * 1024
+        except OSError:
+            pass
     out = [f"<!-- generated:{rnd} begin (tools/profiles_readme.py --round {rnd} --write; do not edit by hand) -->",
            f"Decode GEMV launches of the two metric workloads in `{rnd}_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats` "
-           f"of the bench command); bytes = `ModelSpec.kernel_bytes()`; traffic = `pmc_traffic.json` "
-           f"(`_meta.commit` {traffic.get('_meta', {}).get('commit', '?')}) where the key is unambiguous.",
+           f"of the bench command); bytes = `ModelSpec.kernel_bytes()`; HBM traffic = FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 "
+           f"of the same instantiation in `{rnd}_pmc_<workload>.csv` (separate `--pmc` passes).",
            "",
            "| workload | kernel (instantiation) | calls | avg µs | bytes / launch | TB/s | of 8 TB/s | HBM traffic / algorithmic |",
            "|---|---|---|---|---|---|---|---|"]
@@ -64,8 +74,8 @@ def block(rnd: str) -> str:
         b = binfmt.PRESETS[wl].kernel_bytes()[k]
         us = float(r["avg_us"])
         tbs = b / (us * 1e-6) / 1e12
-        tr = traffic.get(f"{wl}:{k}") if k not in tkey else None
-        ratio = f"{tr['hbm_bytes'] / b:.3f}" if tr else "—"
+        tr = traffic.get((wl, r["kernel"]))
+        ratio = f"{tr / b:.3f}" if tr else "—"
         out.append(f"| {wl} | {k} `{r['kernel']}` | {int(r['calls'])} | {us:.2f} | {b / 1e6:.1f} MB | {tbs:.2f} | "
                    f"{b / (us * 1e-6) / PEAK:.3f} | {ratio} |")
     for tag, fn in (("default command", f"{rnd}_bench.json"), ("driver form `--steps 20 --warmup 5`", f"{rnd}_bench_steps20.json")):

@@ -103,7 +103,7 @@ def main():
             old[k] = v
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
         from kuiperllama_amd.build import kernel_sources_sha1
-        old["_meta"] = {"commit": a.commit or None, "command": a.command,
+        old["_meta"] = {"commit": a.commit or None, "command": a.command, "round": a.round,
                         "kernel_sources_sha1": kernel_sources_sha1(),
                         "note": "HBM bytes per launch from separate rocprofv3 PMC passes; bench.py reads "
                                 "roofline.traffic from this file (it is NOT measured inside a bench run)"}
