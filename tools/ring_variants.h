@@ -2,7 +2,7 @@
 // microbenchmark that measures them (tools/mb_q8ring.hip; profiles/r5_int8_ring_ab.txt):
 //   StagerDma        the input vector staged through the DMA path instead of asm register loads (measured equal)
 //   k_gemv_res_ring  wo / w2 on the ring core   } bit-identical to the register-tile kernels, tie or lose by
-//   k_qkv_ring       qkv on the ring core       } 0.1-0.3 us: the product keeps k_gemv_res / k_qkv
+//   k_qkv_ring       qkv on the ring core       } 0.1-0.3 us inside the model: the product keeps k_gemv_res / k_qkv
 // The ring core itself (kh_q8ring.h) and the two adopted kernels (kh_fused_ring.h: k_ffn13_ring, k_cls_ring) are
 // product headers.
 #pragma once
@@ -15,7 +15,7 @@ __device__ __forceinline__ void dma_x4_keep(const void* base, unsigned voff, uns
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                :
                : "v"(voff), "s"(base), "s"(dst)
-               : "memory");
+               : "memory", "m0");  // see kh_q8ring.h::dma_x4 (built with -w: the reserved-register remark is off)
 }
 
 // Input vector staging through the DMA path - the alternative to StagerAsm, measured equal within 0.5 % on all five
@@ -51,8 +51,9 @@ struct StagerDma {
       if (NORM) dma_x4_keep(wnorm, (unsigned)pc * 1024u + lane16, wr0 + (unsigned)pc * 1024u);
     }
   }
+  // [r6] as Stager / StagerAsm: g = w_norm * x into LDS, the RMS scale returned for the epilogue (kh_gemv.h)
   template <int YOUNGER>
-  __device__ __forceinline__ void finish(float eps, float* red, bool exact) {
+  __device__ __forceinline__ float finish(float eps, float* red, bool exact) {
     if (exact)
       wait_vm<YOUNGER>();
     else
@@ -69,16 +70,31 @@ struct StagerDma {
       xv[v] = xs[ci];
       if (NORM) wv[v] = wraw[ci];
     }
-    float rs = 1.f;
+    float ss = 0.f;
     if (NORM) {
-      float ss = 0.f;
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
         const float t = fma4(xv[v], xv[v], 0.f);
         ss += (act && (int)threadIdx.x + v * wgv < M4) ? t : 0.f;
       }
-      // block_sum over the wgv / 64 waves that staged; its barriers also separate the raw reads above from the
-      // permuted writes below
+    }
+    __syncthreads();  // the raw reads above are done before the permuted writes below
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      const int i = threadIdx.x + v * wgv;
+      if (act && i < M4) {
+        f32x4 t = xv[v];
+        if (NORM) {
+          t.x = wv[v].x * t.x;
+          t.y = wv[v].y * t.y;
+          t.z = wv[v].z * t.z;
+          t.w = wv[v].w * t.w;
+        }
+        xs[q8_slot(i, M16)] = t;
+      }
+    }
+    if (NORM) {
+      // stage_rs over the wgv / 64 waves that staged (threads past VT contribute 0 and write nothing)
       ss = wave_sum(ss);
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nvw = wgv >> 6;
       if (lane == 0 && wave < nvw) red[wave] = ss;
@@ -86,26 +102,10 @@ struct StagerDma {
       float r = 0.f;
 #pragma unroll
       for (int w = 0; w < KH_WAVES_MAX; ++w) r += w < nvw ? red[w < nvw ? w : 0] : 0.f;
-      __syncthreads();
-      rs = 1.0f / sqrtf(r / (float)M + eps);
-    } else {
-      __syncthreads();
-    }
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      const int i = threadIdx.x + v * wgv;
-      if (act && i < M4) {
-        f32x4 t = xv[v];
-        if (NORM) {
-          t.x = wv[v].x * (rs * t.x);
-          t.y = wv[v].y * (rs * t.y);
-          t.z = wv[v].z * (rs * t.z);
-          t.w = wv[v].w * (rs * t.w);
-        }
-        xs[q8_slot(i, M16)] = t;
-      }
+      return 1.0f / sqrtf(r / (float)M + eps);
     }
     __syncthreads();
+    return 1.f;
   }
 };
 
@@ -141,12 +141,16 @@ __global__ __launch_bounds__(1024) void k_gemv_res_ring(const KhGemvResArgs a) {
   ring_pairs<SPLIT, R, false>(
       M, a.gshift, xs, a.K >> 1, lane, red + KH_WAVES_MAX, smem_raw + ring_lds_off(M, false), pair, auxf,
       [&]() __attribute__((always_inline)) { st.issue(); },
-      [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(0.f, red, exact); }, epi);
+      [&](bool exact) __attribute__((always_inline)) { (void)st.template finish<R * 4>(0.f, red, exact); }, epi);
   KH_STAMP_FLUSH();
 }
 
-// RMSNorm(x) -> [wq|wk|wv] row pairs -> +bias -> RoPE -> q / cache row `pos` (k_qkv<true, ...>).  The epilogue
-// operands of a pair - sin, cos of its cache column and the two bias values - come through the scalar cache.
+// stage g = att_norm * x -> [wq|wk|wv] row pairs -> * rs -> +bias -> RoPE -> q / cache row `pos` (k_qkv<true, ...> on
+// the ring core).  The epilogue operands of a pair - sin, cos of its cache column and the two bias values - come
+// through the scalar cache (ld_uniform: no vector load while the ring is live).  [r6] with the one-barrier staging this
+// kernel beats k_qkv by 2.6-2.8 % in the microbenchmark (profiles/r6_q8_phases.txt: 10.45 vs 10.75 us) - and not inside
+// the model (r6_qkv_ring_ab.txt: 11.0 vs 11.1 us back to back, 603.3 vs 604.2 tok/s): built into the product behind
+// plan_ring for that A/B (commit history), measured, and taken out again.
 template <int R, int MAXV, int SPLIT, int STG = 0>
 __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
   extern __shared__ __attribute__((aligned(256))) char smem_raw[];
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
   struct Aux {
     float fci, fcr, b0, b1;
   };
+  float rs = 1.f;
   auto auxf = [&](int p) __attribute__((always_inline)) {
     int which, r0, r1, cidx;
     decode(p, which, r0, r1, cidx);
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
     if (lane != 0) return;
     int which, r0, r1, cidx;
     decode(p, which, r0, r1, cidx);
-    s0 = s0 + x.b0;
-    s1 = s1 + x.b1;
+    s0 = rs * s0 + x.b0;  // the RMS scale of the staged vector, as k_qkv
+    s1 = rs * s1 + x.b1;
     float* dst = sel3(which, q_out, kc + (size_t)pos * kv_dim, vc + (size_t)pos * kv_dim);
     if (which < 2) {
       const float v0 = s0, v1 = s1;
@@ -235,6 +240,6 @@ __global__ __launch_bounds__(1024) void k_qkv_ring(const KhQkvArgs a) {
   ring_pairs<SPLIT, R, false>(
       dim, a.gshift, xs, total, lane, red + KH_WAVES_MAX, smem_raw + ring_lds_off(dim, STG == 0), pair, auxf,
       [&]() __attribute__((always_inline)) { st.issue(); },
-      [&](bool exact) __attribute__((always_inline)) { st.template finish<R * 4>(eps, red, exact); }, epi);
+      [&](bool exact) __attribute__((always_inline)) { rs = st.template finish<R * 4>(eps, red, exact); }, epi);
   KH_STAMP_FLUSH();
 }
