@@ -161,7 +161,7 @@ int dalloc(T** p, size_t n) {
 
 // ---- kh_model_step.hip ----------------------------------------------------------------------
 kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const char* env, int wg = KH_WG,
-                           int wg_max = KH_WG, bool many_waves = false);
+                           int wg_max = KH_WG, bool many_waves = false, bool u3 = false);
 // launch geometry of the five GEMV kernels of a decode step: qkv, wo, ffn13, w2, cls (host-only)
 void plan_decode_shapes(bool quant, int dim, int hidden_dim, int kv_dim, int vocab_size, kh_model::Shape (&out)[5]);
 // which int8 GEMVs of a decode step run on the LDS-DMA ring kernels, and their launch geometry (host-only)

@@ -22,7 +22,7 @@ namespace khm {
 //  u    : 16-byte loads per row per lane in flight (covers the wave's column range when it can);
 //  grid : workgroups, <= 1024 (4 per CU), chosen so every wave gets the same number of items.
 kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const char* env, int wg,
-                           int wg_max, bool many_waves) {
+                           int wg_max, bool many_waves, bool u3) {
   kh_model::Shape sh;
   sh.wg = wg;
   // tuning hook (tools/sweep_shapes.py): KH_SHAPE_<K>="split,u,grid[,wg]" overrides the heuristic
@@ -30,7 +30,7 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
     int sp = 0, u = 0, g = 0, w = wg;
     const int nf = sscanf(ov, "%d,%d,%d,%d", &sp, &u, &g, &w);
     if (nf >= 3 && (sp == 1 || sp == 2 || sp == 4) && sp <= max_split &&
-        (u == 2 || u == 4 || u == 8) && !(quant && u == 8) && g >= 1 && g <= 4096 &&
+        (u == 2 || u == 4 || u == 8 || (quant && u3 && u == 3)) && !(quant && u == 8) && g >= 1 && g <= 4096 &&
         (w == 256 || (w == 512 && wg_max >= 512))) {
       sh.split = sp;
       sh.u = u;
@@ -58,6 +58,10 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
     // one chunk when it covers the column range; ranges that need several chunks anyway take the
     // small one (less padding in the last chunk, finer refill: w2 int8 u4 -> u2 11.9 -> 10.8 us)
     sh.u = per_lane > 4 ? 2 : (per_lane >= 3 ? 4 : 2);
+  // [r6] w2 only (u3): a column range of 5 or 6 loads per lane as TWO exact tiles of 3 instead of three tiles of 2 -
+  // Llama-2-7B int8's w2 (5.4 loads per lane): 10.45 -> 10.25 us, +0.4 % tok/s, four alternations on one box
+  // (profiles/r6_w2_u3_ab.txt); ONE tile of 6 is slower (10.95 us: the whole item requested in one burst)
+  if (quant && u3 && per_lane > 4 && per_lane <= 6) sh.u = 3;
   else
     sh.u = per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
   const int ppw = (wg / KH_WAVE) / sh.split;  // pairs per workgroup per iteration
@@ -330,7 +334,12 @@ void launch_w2(kh_model* m, int l) {
   a.gshift = m->gshift;
   const bool qn = c.is_quant;
   const int kh_launch_wg = m->sh_w2.wg;
-  KH_DISPATCH4X(k_gemv_res, qn, m->sh_w2.u, kh_stage_maxv(c.hidden_dim, kh_launch_wg), m->sh_w2.split, m->sh_w2.grid,
+  const int mv = kh_stage_maxv(c.hidden_dim, kh_launch_wg);
+  if (qn && m->sh_w2.u == 3) {  // two exact tiles of three loads per row (pick_shape, u3)
+    KH_SEL_MV4X(k_gemv_res, true, 3, mv, m->sh_w2.split, m->sh_w2.grid, fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
+    return;
+  }
+  KH_DISPATCH4X(k_gemv_res, qn, m->sh_w2.u, mv, m->sh_w2.split, m->sh_w2.grid,
                 fused_lds_bytes(qn, c.hidden_dim), m->stream, a);
 }
 void launch_cls(kh_model* m) {
@@ -552,7 +561,7 @@ void plan_decode_shapes(bool quant, int dim, int hidden_dim, int kv_dim, int voc
   out[2] = pick_shape(quant, hidden_dim, dim, 1, "KH_SHAPE_FFN", KH_WG, KH_WG_MAX);
   // w2 re-stages the hidden-sized input in every workgroup: 512-thread workgroups halve that
   // L2 -> LDS traffic for the same number of waves (measured 14.1 -> 11.8 us on Llama-3.2-1B)
-  out[3] = pick_shape(quant, dim / 2, hidden_dim, 4, "KH_SHAPE_W2", KH_WG_MAX, KH_WG_MAX, true);
+  out[3] = pick_shape(quant, dim / 2, hidden_dim, 4, "KH_SHAPE_W2", KH_WG_MAX, KH_WG_MAX, true, /*u3=*/true);
   out[4] = pick_shape(quant, (vocab_size + 1) / 2, dim, 1, "KH_SHAPE_CLS", quant ? KH_WG : KH_WG_MAX, KH_WG_MAX);
 }
 
@@ -629,6 +638,7 @@ int configure_step_kernels(kh_model* m) {
     KH_ATTR(false, 4, 1); KH_ATTR(false, 4, 2); KH_ATTR(false, 4, 4);
     KH_ATTR(false, 2, 1); KH_ATTR(false, 2, 2); KH_ATTR(false, 2, 4);
     KH_ATTR(true, 4, 1); KH_ATTR(true, 4, 2); KH_ATTR(true, 4, 4);
+    KH_ATTR(true, 3, 1); KH_ATTR(true, 3, 2); KH_ATTR(true, 3, 4);
     KH_ATTR(true, 2, 1); KH_ATTR(true, 2, 2); KH_ATTR(true, 2, 4);
 #undef KH_ATTR
   }

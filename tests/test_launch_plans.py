@@ -22,7 +22,8 @@ def test_decode_plan_invariants(name):
     max_split = {"qkv": 2, "wo": 4, "ffn13": 1, "w2": 4, "cls": 1}
     for k, s in plan.items():
         assert s["split"] in (1, 2, 4) and s["split"] <= max_split[k], (k, s)
-        assert s["u"] in ((2, 4) if sp.quant else (2, 4, 8)), (k, s)
+        # int8 w2 alone may take two exact tiles of three loads per row (round 6, profiles/r6_w2_u3_ab.txt)
+        assert s["u"] in (((2, 3, 4) if k == "w2" else (2, 4)) if sp.quant else (2, 4, 8)), (k, s)
         assert s["wg"] in (256, 512), (k, s)
         assert 1 <= s["grid"] <= 1024, (k, s)  # never more than 4 x 256-thread workgroups per CU
         # a split part still streams a useful number of bytes per row pair
@@ -43,7 +44,7 @@ def test_decode_plan_documented_shapes(monkeypatch):
     assert plan["qkv"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
     assert plan["wo"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
     assert plan["ffn13"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
-    assert plan["w2"] == {"split": 2, "u": 2, "grid": 512, "wg": 512}
+    assert plan["w2"] == {"split": 2, "u": 3, "grid": 512, "wg": 512}  # 5.4 loads per lane: two tiles of three
     assert plan["cls"] == {"split": 1, "u": 4, "grid": 512, "wg": 256}
     sp = binfmt.PRESETS["llama3.2-1b"]
     plan = _ffi.plan_decode_shapes(sp.dim, sp.hidden_dim, sp.kv_dim, sp.vocab_size, False)
