@@ -54,16 +54,17 @@ kh_model::Shape pick_shape(bool quant, int pairs, int M, int max_split, const ch
     sh.split *= 2;
   const int Mc = quant ? M / 16 : M / 4;
   const int per_lane = ((Mc + sh.split - 1) / sh.split + KH_WAVE - 1) / KH_WAVE;
-  if (quant)
+  if (quant) {
     // one chunk when it covers the column range; ranges that need several chunks anyway take the
     // small one (less padding in the last chunk, finer refill: w2 int8 u4 -> u2 11.9 -> 10.8 us)
     sh.u = per_lane > 4 ? 2 : (per_lane >= 3 ? 4 : 2);
-  // [r6] w2 only (u3): a column range of 5 or 6 loads per lane as TWO exact tiles of 3 instead of three tiles of 2 -
-  // Llama-2-7B int8's w2 (5.4 loads per lane): 10.45 -> 10.25 us, +0.4 % tok/s, four alternations on one box
-  // (profiles/r6_w2_u3_ab.txt); ONE tile of 6 is slower (10.95 us: the whole item requested in one burst)
-  if (quant && u3 && per_lane > 4 && per_lane <= 6) sh.u = 3;
-  else
+    // [r6] w2 only (u3): a column range of 5 or 6 loads per lane as TWO exact tiles of 3 instead of three tiles of
+    // 2 - Llama-2-7B int8's w2 (5.4 loads per lane): 10.45 -> 10.25 us, +0.4 % tok/s, four alternations on one box
+    // (profiles/r6_w2_u3_ab.txt); ONE tile of 6 is slower (10.95 us: the whole item requested in one burst)
+    if (u3 && per_lane > 4 && per_lane <= 6) sh.u = 3;
+  } else {
     sh.u = per_lane >= 8 ? 8 : (per_lane >= 3 ? 4 : 2);
+  }
   const int ppw = (wg / KH_WAVE) / sh.split;  // pairs per workgroup per iteration
   const int need = (pairs + ppw - 1) / ppw;
   // every workgroup re-stages the M-float input vector from L2: keep that below ~75 % of the

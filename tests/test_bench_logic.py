@@ -52,6 +52,18 @@ def test_algorithmic_bytes_match_survey_table():
     assert bench.ffn13_bytes(p["llama3.2-1b"]) == 2 * 8192 * 2048 * 4 + 2 * 2048 * 4 + 8192 * 4
     n = 2 * 11008 * 4096
     assert bench.ffn13_bytes(p["llama2-7b-int8"]) == n + n // 64 * 4 + 2 * 4096 * 4 + 11008 * 4
+    # per-launch bytes of every weight-streaming kernel (DESIGN 3.2's table, profiles/README.md's generated tables)
+    kb = p["llama3.2-1b"].kernel_bytes()
+    assert kb["ffn13"] == bench.ffn13_bytes(p["llama3.2-1b"]) == 134266880
+    assert [round(kb[k] / 1e6, 1) for k in ("qkv", "wo", "w2", "cls")] == [25.2, 16.8, 67.2, 1051.2]
+    kq = p["llama2-7b-int8"].kernel_bytes()
+    assert kq["ffn13"] == bench.ffn13_bytes(p["llama2-7b-int8"])
+    assert [round(kq[k] / 1e6, 1) for k in ("qkv", "wo", "w2", "cls")] == [53.6, 17.9, 48.0, 139.4]
+    # the five kernels x L layers + classifier carry the weight bytes of a token
+    for name in ("llama3.2-1b", "llama2-7b-int8"):
+        sp, k = p[name], p[name].kernel_bytes()
+        per_tok = sp.n_layers * (k["qkv"] + k["wo"] + k["ffn13"] + k["w2"]) + k["cls"]
+        assert abs(per_tok / sp.algorithmic_bytes_per_token(0) - 1) < 0.005
 
 
 def test_traffic_provenance_names_the_kernel_sources():

@@ -35,6 +35,23 @@ def test_decode_plan_invariants(name):
         assert s["grid"] <= -(-max(pairs, 1) // pairs_per_wg) or s["grid"] % 256 == 0, (k, s)
 
 
+def test_decode_plan_int8_wide_rows_keep_the_small_tile():
+    """int8 rows that need more than four 16-byte loads per lane walk several tiles of TWO loads (qkv / wo / ffn13 /
+    cls; w2 takes two tiles of three where that is exact) - never the fp32 rule's 4 or 8.  Geometries wider than any
+    preset, so that the branch is exercised (a dangling `else` once sent every int8 launch but w2 through the fp32
+    rule: invisible at the presets, whose int8 rows need at most four loads per lane)."""
+    for dim, hidden in ((8192, 28672), (6144, 16384), (5120, 13824)):
+        plan = _ffi.plan_decode_shapes(dim, hidden, dim, 32000, True)
+        for k, s in plan.items():
+            per_lane = -(-(-(-(hidden if k == "w2" else dim) // 16 // s["split"])) // 64)
+            if per_lane > 4:
+                want = (3,) if k == "w2" and per_lane <= 6 else (2,)
+                assert s["u"] in want, (dim, hidden, k, s, per_lane)
+            assert s["u"] in (2, 3, 4), (k, s)
+    # fp32 keeps its own rule: eight loads per lane when the row covers them
+    assert _ffi.plan_decode_shapes(8192, 28672, 8192, 32000, False)["ffn13"]["u"] == 8
+
+
 def test_decode_plan_documented_shapes(monkeypatch):
     """The shapes DESIGN.md 3.2 quotes for the two bench workloads."""
     for k in ("QKV", "WO", "FFN", "W2", "CLS"):
