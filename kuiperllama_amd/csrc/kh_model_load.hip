@@ -15,6 +15,8 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <mutex>
+#include <utility>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -319,6 +321,52 @@ size_t expected_weight_bytes(const kh_config& c) {
 // Hook KH_KV_VMM=0 (or a runtime without the virtual-memory API): one plain allocation, as before.
 static int kv_ensure_impl(kh_model* m, int row0, int rows, int layer);
 static void kv_release(kh_model* m);
+// Address ranges outlive the model that reserved them: kv_release hands a range (every chunk unmapped) to this
+// process-wide list and the next model whose caches reserve the same number of bytes takes it over; the list is never
+// emptied.  hipMemAddressFree is NOT called: on this runtime (ROCm 7.2) it dereferences a null pointer once in a few
+// thousand create / destroy cycles of a process that keeps mapping and unmapping chunks (tools/stress_destroy.py under
+// tools/dbg/segv_bt.c: the second of kv_release's two calls, inside libamdhip64; seen once in five runs of the GPU
+// suite, `profiles/r6_vmm_destroy_crash.txt`; the plain allocation survives 28 000 cycles).  A reservation is address
+// space only - no HBM, no page tables until a chunk is mapped - so the cost of keeping it is a few dozen distinct
+// sizes of a 47-bit space in the worst process this library has seen (its own test suite).
+// Hook KH_KV_VA_POOL=0: free the ranges as rounds 6's first version did (the stress tool uses it to show the crash).
+struct VaPool {
+  std::mutex mu;
+  std::vector<std::pair<void*, size_t>> ranges;
+};
+static VaPool& va_pool() {
+  static VaPool* p = new VaPool();  // never destroyed: models may be released from static destructors
+  return *p;
+}
+static void* va_take(size_t bytes, size_t align) {
+  {
+    VaPool& vp = va_pool();
+    std::lock_guard<std::mutex> g(vp.mu);
+    for (size_t i = 0; i < vp.ranges.size(); ++i)
+      if (vp.ranges[i].second == bytes) {
+        void* p = vp.ranges[i].first;
+        vp.ranges[i] = vp.ranges.back();
+        vp.ranges.pop_back();
+        return p;
+      }
+  }
+  void* p = nullptr;
+  if (hipMemAddressReserve(&p, bytes, align, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+static void va_give(void* p, size_t bytes) {
+  if (!p) return;
+  if (dbg_off("KH_KV_VA_POOL")) {
+    (void)hipMemAddressFree(p, bytes);
+    return;
+  }
+  VaPool& vp = va_pool();
+  std::lock_guard<std::mutex> g(vp.mu);
+  vp.ranges.emplace_back(p, bytes);
+}
 static int kv_allocate(kh_model* m) {
   const kh_config& c = m->cfg;
   const size_t total = (size_t)c.layer_num * (size_t)c.cache_len * c.kv_dim * sizeof(float);
@@ -333,9 +381,9 @@ static int kv_allocate(kh_model* m) {
       size_t chunk = (size_t)8 << 20;  // ONE size for every mapping of every model in the process (see kv_ensure)
       chunk = (chunk + gran - 1) / gran * gran;
       const size_t reserved = (total + chunk - 1) / chunk * chunk;
-      void *pk = nullptr, *pv = nullptr;
-      if (hipMemAddressReserve(&pk, reserved, chunk, nullptr, 0) == hipSuccess) {
-        if (hipMemAddressReserve(&pv, reserved, chunk, nullptr, 0) == hipSuccess) {
+      void *pk = va_take(reserved, chunk), *pv = nullptr;
+      if (pk) {
+        if ((pv = va_take(reserved, chunk)) != nullptr) {
           kv.on = true;
           kv.chunk = chunk;
           kv.reserved = reserved;
@@ -350,7 +398,7 @@ static int kv_allocate(kh_model* m) {
           kv_release(m);
           kv = kh_model::KvVmm();
         } else {
-          (void)hipMemAddressFree(pk, reserved);
+          va_give(pk, reserved);
         }
       }
     }
@@ -371,8 +419,8 @@ static void kv_release(kh_model* m) {
       (void)hipMemRelease(r.h);
     }
     kv.runs.clear();
-    if (m->kcache) (void)hipMemAddressFree(m->kcache, kv.reserved);
-    if (m->vcache) (void)hipMemAddressFree(m->vcache, kv.reserved);
+    if (m->kcache) va_give(m->kcache, kv.reserved);
+    if (m->vcache) va_give(m->vcache, kv.reserved);
     kv.on = false;
   }
   m->kcache = m->vcache = nullptr;

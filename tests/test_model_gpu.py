@@ -436,6 +436,45 @@ def test_kv_cache_is_reserved_and_mapped_on_demand(gpu, oracle, monkeypatch):
     _ffi.sync_env()
 
 
+def test_kv_address_ranges_are_recycled_not_freed(gpu, oracle):
+    """kh_model_destroy hands the two reserved KV ranges (every chunk unmapped) to a process-wide list instead of
+    calling hipMemAddressFree - that call dereferences a null pointer inside the runtime once in a few thousand
+    create / destroy cycles (profiles/r6_vmm_destroy_crash.txt; it took down one GPU-suite run in five).  The next
+    model of the same cache size takes the ranges over: same addresses, nothing committed beyond what creation maps,
+    rows a previous owner wrote read as zeros again, and the decode is the oracle's.  200 cycles on top."""
+    from kuiperllama_amd.model import KuiperModel
+    spec = binfmt.ModelSpec(512, 1408, 3, 8, 2, 640, 8192, True, binfmt.FAMILY_LLAMA, False, 64,
+                            binfmt.ROPE_HALF, 500000.0, 1e-5, "kv-recycle")
+    img_d, img_h = _synth(spec, 23, gpu, wander=True)
+    a = KuiperModel.from_device_image(img_d, spec)
+    reserved, committed_a = a.kv_bytes()
+    if committed_a == reserved:
+        a.close()
+        pytest.skip("this runtime took the plain allocation (no virtual-memory API)")
+    rng = np.random.default_rng(1)
+    rows = rng.standard_normal((16, spec.kv_dim), dtype=np.float32)
+    a.write_kv(2, 6000, rows, -rows)  # a chunk only this model mapped
+    a.write_kv(0, 0, rows, -rows)     # and rows every model maps at creation
+    assert a.kv_bytes()[1] > committed_a
+    addr_a = a.kv_cache_ptrs()        # (commits everything; this model is about to go)
+    a.close()
+    b = KuiperModel.from_device_image(img_d, spec)
+    assert b.kv_bytes() == (reserved, committed_a)
+    k, v = b.read_kv(0, 0, 16)
+    assert not k.any() and not v.any()
+    k, v = b.read_kv(2, 6000, 16)
+    assert not k.any() and not v.any()
+    want = oracle.OracleModel.from_spec(img_h, spec).generate([1, 7, 300], 40)
+    assert b.generate([1, 7, 300], 40, exec="graph")[0] == want
+    assert b.kv_cache_ptrs() == addr_a
+    b.close()
+    for i in range(200):
+        m = KuiperModel.from_device_image(img_d, spec)
+        if i % 50 == 0:
+            assert m.generate([1, 7, 300], 40, exec="graph")[0] == want
+        m.close()
+
+
 def test_loader_entry_points_agree(gpu):
     from kuiperllama_amd.model import KuiperModel
     spec, img, toks, ref = load_golden("ref_llama_mha_untied")
