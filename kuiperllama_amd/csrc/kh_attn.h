@@ -197,6 +197,9 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 #ifndef KH_ATTN_UB
 #define KH_ATTN_UB 4
 #endif
+#ifndef KH_ATTN_FOLD1
+#define KH_ATTN_FOLD1 0  // 1: the one-barrier fold of attn_fast_partial (round-6 experiment, profiles/r6_attn_fold_ab.txt)
+#endif
 #ifndef KH_ATTN_MIN_TS
 #define KH_ATTN_MIN_TS 256  // timesteps a head keeps in ONE split; also the split quantum of the GQA group path
 #endif
@@ -409,6 +412,53 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
     KH_ATTN_STAMP(3);
     KH_ATTN_STAMP_W(1);
   }
+#if KH_ATTN_FOLD1
+  // ---- merge the TPI groups, ONE barrier [r6 experiment]: every wave folds its own lane groups against the WAVE's
+  // maximum (no workgroup-wide maximum first, hence no barrier before the rescale), leaves (max, l, o[hs]) in LDS, and
+  // the reader weighs the eight wave partials by exp(max_w - M).  The coefficients are computed by lanes 0..7 of every
+  // wave (one expf per lane, not eight per thread) and broadcast through SGPRs.
+  {
+    const float mw = across_groups_max<G>(m);
+    const float mwr = mw == -INFINITY ? 0.f : mw;  // a wave whose groups saw no timestep: every factor exp(-inf) = 0
+    const float f = expf(m - mwr);
+    l = across_groups_sum<G>(l * f);
+    o.x = across_groups_sum<G>(o.x * f);
+    o.y = across_groups_sum<G>(o.y * f);
+    o.z = across_groups_sum<G>(o.z * f);
+    o.w = across_groups_sum<G>(o.w * f);
+    if (lane < G && active) ((f32x4*)(opart + wave * hs))[dl] = o;
+    if (lane == 0) {
+      red[wave] = mw;
+      lpart[wave] = l;
+    }
+    __syncthreads();
+    const int nw = kh_nwaves();
+    const f32x4 ra = ((const f32x4*)red)[0], rb = ((const f32x4*)red)[1];
+    const float mv[KH_WAVES_MAX] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+    float M = mv[0];
+#pragma unroll
+    for (int w = 1; w < KH_WAVES_MAX; ++w) M = fmaxf(M, w < nw ? mv[w] : -INFINITY);
+    float mine = mv[0];
+#pragma unroll
+    for (int w = 1; w < KH_WAVES_MAX; ++w) mine = lane == w ? mv[w] : mine;
+    const float cl = (lane < nw) ? expf(mine - M) : 0.f;  // M is finite: every split owns a valid timestep
+    float c[KH_WAVES_MAX];
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_MAX; ++w) c[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl), w));
+    float r = 0.f, L = 0.f;
+    if (tid < hs) {
+#pragma unroll
+      for (int w = 0; w < KH_WAVES_MAX; ++w) {
+        const int wc = w < nw ? w : 0;
+        r = __builtin_fmaf(c[w], opart[wc * hs + tid], r);  // c[w] = 0 for absent waves
+        L = __builtin_fmaf(c[w], lpart[wc], L);
+      }
+    }
+    r_out = r;
+    L_out = L;
+    return M;
+  }
+#endif
   // ---- merge the TPI groups: common max, rescale, sum ------------------------------------
   float mw = across_groups_max<G>(m);
   if (lane == 0) red[wave] = mw;
