@@ -172,8 +172,8 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 //    memory round trip instead of K-then-V;
 //  * every G-lane group keeps its own running (max, sum, o) in registers (flash-style), so
 //    there is no score buffer and no workgroup-wide max/sum pass; the q.k reduction is DPP;
-//  * groups are merged once at the end: permlane swaps inside the wave, one LDS exchange across
-//    the 4 waves (2 barriers in the whole kernel).
+//  * groups are merged once at the end: permlane swaps inside the wave against the wave's own maximum, one
+//    LDS exchange across the waves (ONE barrier in the whole kernel since round 6).
 // G = lanes per timestep = pow2 >= hs/4, must be 16, 32 or 64 (hs 33..256).
 //
 // Long contexts: the grid carries NS workgroups per head ("splits"); at run time the first
@@ -196,9 +196,6 @@ __device__ __forceinline__ void attn_head_decode(const float* __restrict__ q_h,
 //    XCDs) and never waits on another workgroup, so it cannot hang.  The merger re-arms the ticket.
 #ifndef KH_ATTN_UB
 #define KH_ATTN_UB 4
-#endif
-#ifndef KH_ATTN_FOLD1
-#define KH_ATTN_FOLD1 0  // 1: the one-barrier fold of attn_fast_partial (round-6 experiment, profiles/r6_attn_fold_ab.txt)
 #endif
 #ifndef KH_ATTN_MIN_TS
 #define KH_ATTN_MIN_TS 256  // timesteps a head keeps in ONE split; also the split quantum of the GQA group path
@@ -412,77 +409,47 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
     KH_ATTN_STAMP(3);
     KH_ATTN_STAMP_W(1);
   }
-#if KH_ATTN_FOLD1
-  // ---- merge the TPI groups, ONE barrier [r6 experiment]: every wave folds its own lane groups against the WAVE's
-  // maximum (no workgroup-wide maximum first, hence no barrier before the rescale), leaves (max, l, o[hs]) in LDS, and
-  // the reader weighs the eight wave partials by exp(max_w - M).  The coefficients are computed by lanes 0..7 of every
-  // wave (one expf per lane, not eight per thread) and broadcast through SGPRs.
-  {
-    const float mw = across_groups_max<G>(m);
-    const float mwr = mw == -INFINITY ? 0.f : mw;  // a wave whose groups saw no timestep: every factor exp(-inf) = 0
-    const float f = expf(m - mwr);
-    l = across_groups_sum<G>(l * f);
-    o.x = across_groups_sum<G>(o.x * f);
-    o.y = across_groups_sum<G>(o.y * f);
-    o.z = across_groups_sum<G>(o.z * f);
-    o.w = across_groups_sum<G>(o.w * f);
-    if (lane < G && active) ((f32x4*)(opart + wave * hs))[dl] = o;
-    if (lane == 0) {
-      red[wave] = mw;
-      lpart[wave] = l;
-    }
-    __syncthreads();
-    const int nw = kh_nwaves();
-    const f32x4 ra = ((const f32x4*)red)[0], rb = ((const f32x4*)red)[1];
-    const float mv[KH_WAVES_MAX] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-    float M = mv[0];
-#pragma unroll
-    for (int w = 1; w < KH_WAVES_MAX; ++w) M = fmaxf(M, w < nw ? mv[w] : -INFINITY);
-    float mine = mv[0];
-#pragma unroll
-    for (int w = 1; w < KH_WAVES_MAX; ++w) mine = lane == w ? mv[w] : mine;
-    const float cl = (lane < nw) ? expf(mine - M) : 0.f;  // M is finite: every split owns a valid timestep
-    float c[KH_WAVES_MAX];
-#pragma unroll
-    for (int w = 0; w < KH_WAVES_MAX; ++w) c[w] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl), w));
-    float r = 0.f, L = 0.f;
-    if (tid < hs) {
-#pragma unroll
-      for (int w = 0; w < KH_WAVES_MAX; ++w) {
-        const int wc = w < nw ? w : 0;
-        r = __builtin_fmaf(c[w], opart[wc * hs + tid], r);  // c[w] = 0 for absent waves
-        L = __builtin_fmaf(c[w], lpart[wc], L);
-      }
-    }
-    r_out = r;
-    L_out = L;
-    return M;
-  }
-#endif
-  // ---- merge the TPI groups: common max, rescale, sum ------------------------------------
-  float mw = across_groups_max<G>(m);
-  if (lane == 0) red[wave] = mw;
-  __syncthreads();
-  float M = red[0];
-  const int nw = kh_nwaves();
-#pragma unroll
-  for (int w = 1; w < KH_WAVES_MAX; ++w) M = fmaxf(M, red[w < nw ? w : 0]);
-  const float f = expf(m - M);  // groups that saw no timestep have m = -inf -> 0
+  // ---- merge the TPI groups: ONE barrier [r6] ---------------------------------------------------------------------
+  // Every wave folds its own lane groups against the WAVE's maximum - no workgroup-wide maximum first, hence no
+  // barrier (and no LDS round trip) in front of the rescale -, leaves (max_w, l_w, o_w[hs]) in LDS, and the reader
+  // weighs the wave partials by c_w = exp(max_w - M).  The coefficients are computed by lanes 0..7 of every wave (one
+  // expf per lane instead of eight per thread) and broadcast through SGPRs (v_readlane).  Rounds 1-5 folded in two
+  // steps (workgroup maximum through LDS, barrier, rescale + wave sums, LDS, barrier, plain sums): same-box,
+  // alternating three times, the launch went 3.58 -> 3.36 us (Llama-3.2-1B), 4.96 -> 4.80 (Llama-2-7B), tok/s +0.45 %
+  // / +0.4 % / +0.75 % (TinyLlama) / +0.7 % (Qwen2.5-0.5B), same tokens (profiles/r6_attn_fold_ab.txt).
+  const float mw = across_groups_max<G>(m);
+  const float mwr = mw == -INFINITY ? 0.f : mw;  // a wave whose groups saw no timestep: every factor is exp(-inf) = 0
+  const float f = expf(m - mwr);
   l = across_groups_sum<G>(l * f);
   o.x = across_groups_sum<G>(o.x * f);
   o.y = across_groups_sum<G>(o.y * f);
   o.z = across_groups_sum<G>(o.z * f);
   o.w = across_groups_sum<G>(o.w * f);
   if (lane < G && active) ((f32x4*)(opart + wave * hs))[dl] = o;
-  if (lane == 0) lpart[wave] = l;
+  if (lane == 0) {
+    red[wave] = mw;
+    lpart[wave] = l;
+  }
   __syncthreads();
-  float r = 0.f, L = 0.f;
-  if (tid < hs) {
+  static_assert(KH_WAVES_MAX == 8, "red[] is read as two float4");
+  const int nw = kh_nwaves();
+  const f32x4 ra = ((const f32x4*)red)[0], rb = ((const f32x4*)red)[1];
+  const float mv[KH_WAVES_MAX] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+  float M = mv[0], mine = mv[0];
 #pragma unroll
-    for (int w = 0; w < KH_WAVES_MAX; ++w) {
-      const int wc = w < nw ? w : 0;
-      r += w < nw ? opart[wc * hs + tid] : 0.f;
-      L += w < nw ? lpart[wc] : 0.f;
+  for (int w = 1; w < KH_WAVES_MAX; ++w) {
+    M = fmaxf(M, w < nw ? mv[w] : -INFINITY);  // words of absent waves were never written
+    mine = lane == w ? mv[w] : mine;
+  }
+  const float cl = lane < nw ? expf(mine - M) : 0.f;  // M is finite: every split owns a valid timestep
+  float r = 0.f, L = 0.f;
+#pragma unroll
+  for (int w = 0; w < KH_WAVES_MAX; ++w) {
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl), w));  // 0 for an absent wave
+    const int wc = w < nw ? w : 0;
+    if (tid < hs) {
+      r = __builtin_fmaf(c, opart[wc * hs + tid], r);
+      L = __builtin_fmaf(c, lpart[wc], L);
     }
   }
   r_out = r;
