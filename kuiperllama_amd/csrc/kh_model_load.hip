@@ -342,11 +342,10 @@ static void* va_take(size_t bytes, size_t align) {
   {
     VaPool& vp = va_pool();
     std::lock_guard<std::mutex> g(vp.mu);
-    for (size_t i = 0; i < vp.ranges.size(); ++i)
+    for (size_t i = vp.ranges.size(); i-- > 0;)  // the most recently released range of that size first
       if (vp.ranges[i].second == bytes) {
         void* p = vp.ranges[i].first;
-        vp.ranges[i] = vp.ranges.back();
-        vp.ranges.pop_back();
+        vp.ranges.erase(vp.ranges.begin() + (long)i);
         return p;
       }
   }

@@ -466,7 +466,7 @@ def test_kv_address_ranges_are_recycled_not_freed(gpu, oracle):
     assert not k.any() and not v.any()
     want = oracle.OracleModel.from_spec(img_h, spec).generate([1, 7, 300], 40)
     assert b.generate([1, 7, 300], 40, exec="graph")[0] == want
-    assert b.kv_cache_ptrs() == addr_a
+    assert set(b.kv_cache_ptrs()) == set(addr_a)  # the two ranges a released last, in either role
     b.close()
     for i in range(200):
         m = KuiperModel.from_device_image(img_d, spec)
