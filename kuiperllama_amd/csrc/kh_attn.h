@@ -759,19 +759,15 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
     KH_ATTN_STAMP(3);
     KH_ATTN_STAMP_W(1);
   }
-  // ---- merge the lane groups of a wave, then the waves -----------------------------------------
+  // ---- merge the lane groups of a wave, then the waves: ONE barrier [r6], as attn_fast_partial -------------------
+  // every wave folds its lane groups against its own maximum, (max, l, o) of the wave go to LDS, the reader weighs
+  // the wave partials by exp2(max_w - M) (the hardware exp2: eight per thread cost less than the barrier + LDS round
+  // trip of the two-step fold of rounds 1-5)
 #pragma unroll
   for (int j = 0; j < KVM; ++j) {
     const float mw = across_groups_max<G>(m[j]);
-    if (lane == 0) red[wave * KVM + j] = mw;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < KVM; ++j) {
-    float M2 = red[j];
-#pragma unroll
-    for (int w = 1; w < KH_WAVES_MAX; ++w) M2 = fmaxf(M2, red[(w < nw ? w : 0) * KVM + j]);
-    const float f = __builtin_amdgcn_exp2f(m[j] - M2);  // groups without a timestep: m = -inf -> 0
+    const float mwr = mw == -INFINITY ? 0.f : mw;  // a wave without a timestep: every factor exp2(-inf) = 0
+    const float f = __builtin_amdgcn_exp2f(m[j] - mwr);
     const float lw = across_groups_sum<G>(l[j] * f);
     f32x4 ow;
     ow.x = across_groups_sum<G>(o[j].x * f);
@@ -779,18 +775,28 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
     ow.z = across_groups_sum<G>(o[j].z * f);
     ow.w = across_groups_sum<G>(o[j].w * f);
     if (lane < G && active) ((f32x4*)(opart + (size_t)(wave * KVM + j) * hs))[dl] = ow;
-    if (lane == 0) lpart[wave * KVM + j] = lw;
+    if (lane == 0) {
+      red[wave * KVM + j] = mw;
+      lpart[wave * KVM + j] = lw;
+    }
   }
   __syncthreads();
   float r = 0.f, L = 0.f, M2 = -INFINITY;
   if (tid < KVM * hs) {
     const int j = tid / hs, e = tid - j * hs;
+    float mv[KH_WAVES_MAX];
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_MAX; ++w) {
+      mv[w] = w < nw ? red[w * KVM + j] : -INFINITY;  // words of absent waves were never written
+      M2 = fmaxf(M2, mv[w]);
+    }
+    // M2 is finite: every split owns a valid timestep (use_batch's precondition)
 #pragma unroll
     for (int w = 0; w < KH_WAVES_MAX; ++w) {
       const int wc = w < nw ? w : 0;
-      r += w < nw ? opart[(size_t)(wc * KVM + j) * hs + e] : 0.f;
-      L += w < nw ? lpart[wc * KVM + j] : 0.f;
-      M2 = fmaxf(M2, red[wc * KVM + j]);
+      const float c = __builtin_amdgcn_exp2f(mv[w] - M2);  // 0 for a wave without a timestep / an absent wave
+      r = __builtin_fmaf(c, opart[(size_t)(wc * KVM + j) * hs + e], r);
+      L = __builtin_fmaf(c, lpart[wc * KVM + j], L);
     }
   }
   r_out = r;
