@@ -3,6 +3,7 @@
 # address ranges kept (default), freed with hipMemAddressFree (KH_KV_VA_POOL=0: crashes), plain allocation
 cd "$(dirname "$0")/.."
 O=gpurun_out; mkdir -p $O
+[ -f tools/dbg/libsegv_bt.so ] || gcc -shared -fPIC -O1 -o tools/dbg/libsegv_bt.so tools/dbg/segv_bt.c
 export LD_PRELOAD=$PWD/tools/dbg/libsegv_bt.so
 F=$O/r6_vmm_destroy_crash.txt; : > $F
 run() { echo "== $*" >> $F; ( env "$@" timeout 500 python tools/stress_destroy.py $T 2>&1; echo "rc=$?" ) | grep -v -E "^Extension|amdgpu.ids|^python\(|libffi|_ctypes" | cut -c1-200 >> $F; }
