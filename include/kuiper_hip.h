@@ -242,7 +242,10 @@ int kh_model_get_kv(kh_model* m, float** d_kcache, float** d_vcache);
 /* bytes of the KV cache: *reserved = the address range of [layer, cache_len, kv_dim] floats x 2 (the reference's
  * up-front allocation, llama3.cpp:469-472), *committed = HBM actually backing it now.  The range is reserved at
  * creation and memory is mapped in 8-MiB chunks as generate / predict / prefill / kh_model_write_kv first reach
- * rows (hook KH_KV_VMM=0: one plain allocation, committed == reserved).  kh_model_get_kv commits everything. */
+ * rows (hook KH_KV_VMM=0: one plain allocation, committed == reserved).  kh_model_get_kv commits everything.
+ * kh_model_destroy releases the memory but keeps the two address ranges in a process-wide list for the next model
+ * with caches of the same size (hipMemAddressFree is never called: it crashes inside the runtime after 1000-2000
+ * create / destroy cycles, profiles/r6_vmm_destroy_crash.txt). */
 int kh_model_kv_bytes(const kh_model* m, int64_t* reserved, int64_t* committed);
 /* copy rows [row0, row0+nrows) of one layer's K and V cache to host (tests) */
 int kh_model_read_kv(kh_model* m, int32_t layer, int32_t row0, int32_t nrows, float* h_k,
