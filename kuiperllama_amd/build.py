@@ -93,6 +93,8 @@ def build_variant(name: str, defines: list[str], commit: str | None = None) -> s
     od = os.path.join(LIB_DIR, "_" + name)
     os.makedirs(od, exist_ok=True)
     for src in SOURCES:
+        if not os.path.exists(os.path.join(CSRC, src)):  # --variant-at an older commit: that source came later
+            continue
         obj = os.path.join(od, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-w"] + \
               [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
