@@ -414,9 +414,9 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
   // barrier (and no LDS round trip) in front of the rescale -, leaves (max_w, l_w, o_w[hs]) in LDS, and the reader
   // weighs the wave partials by c_w = exp(max_w - M).  The coefficients are computed by lanes 0..7 of every wave (one
   // expf per lane instead of eight per thread) and broadcast through SGPRs (v_readlane).  Rounds 1-5 folded in two
-  // steps (workgroup maximum through LDS, barrier, rescale + wave sums, LDS, barrier, plain sums): same-box,
-  // alternating three times, the launch went 3.58 -> 3.36 us (Llama-3.2-1B), 4.96 -> 4.80 (Llama-2-7B), tok/s +0.45 %
-  // / +0.4 % / +0.75 % (TinyLlama) / +0.7 % (Qwen2.5-0.5B), same tokens (profiles/r6_attn_fold_ab.txt).
+  // steps (workgroup maximum through LDS, barrier, rescale + wave sums, LDS, barrier, plain sums): same box as round
+  // 5's library, alternating three times, the launch went 3.52 -> 3.37 us (Llama-3.2-1B), 4.93 -> 4.64 (Llama-2-7B),
+  // same tokens (profiles/r6_attn_fold_ab.txt, r6_attn_fold_reader_ab.txt).
   const float mw = across_groups_max<G>(m);
   const float mwr = mw == -INFINITY ? 0.f : mw;  // a wave whose groups saw no timestep: every factor is exp(-inf) = 0
   const float f = expf(m - mwr);
@@ -442,15 +442,23 @@ __device__ __forceinline__ float attn_fast_partial(const float* q_h, const float
     mine = lane == w ? mv[w] : mine;
   }
   const float cl = lane < nw ? expf(mine - M) : 0.f;  // M is finite: every split owns a valid timestep
+  // Branch-free reader: every thread reads (threads past the head vector a clamped element; their r is never used),
+  // so the sixteen LDS reads leave together.  (With the reads behind `if (tid < hs)` inside the unrolled loop the
+  // compiler built eight exec-masked regions, each with its own s_waitcnt lgkmcnt(0): eight LDS round trips in a row,
+  // +0.3 us on the launch - seen in the ISA after a same-box run against round 5 read 3.68 us where the experiment
+  // build of this fold had read 3.36.)
+  const int te = tid < hs ? tid : 0;
+  const f32x4 la = ((const f32x4*)lpart)[0], lb = ((const f32x4*)lpart)[1];
+  const float lv[KH_WAVES_MAX] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+  float ov[KH_WAVES_MAX];
+#pragma unroll
+  for (int w = 0; w < KH_WAVES_MAX; ++w) ov[w] = opart[(w < nw ? w : 0) * hs + te];
   float r = 0.f, L = 0.f;
 #pragma unroll
   for (int w = 0; w < KH_WAVES_MAX; ++w) {
     const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cl), w));  // 0 for an absent wave
-    const int wc = w < nw ? w : 0;
-    if (tid < hs) {
-      r = __builtin_fmaf(c, opart[wc * hs + tid], r);
-      L = __builtin_fmaf(c, lpart[wc], L);
-    }
+    r = __builtin_fmaf(c, ov[w], r);
+    L = __builtin_fmaf(c, w < nw ? lv[w] : 0.f, L);  // words of absent waves were never written
   }
   r_out = r;
   L_out = L;

@@ -197,6 +197,21 @@ def test_long_generate_crosses_attention_splits(gpu, oracle):
     got3, _ = m2.generate([1, 2, 3], steps, exec="graph")
     assert got3 == want, next(i for i, (a, b) in enumerate(zip(got3, want)) if a != b)
     m2.close()
+    # and with 256-thread attention workgroups (tuning hook KH_ATTN_WG): FOUR waves take part in the one-barrier
+    # fold of the lane groups, the reduction words of waves 4..7 are never written (kh_attn.h, round 6) - per-head
+    # path and group path
+    for tlong in (None, "300"):
+        os.environ["KH_ATTN_WG"] = "256"
+        if tlong:
+            os.environ["KH_ATTN_TLONG"] = tlong
+        try:
+            m3 = KuiperModel.from_device_image(img_d, spec)
+        finally:
+            del os.environ["KH_ATTN_WG"]
+            os.environ.pop("KH_ATTN_TLONG", None)
+        got4, _ = m3.generate([1, 2, 3], steps, exec="graph")
+        assert got4 == want, (tlong, next(i for i, (a, b) in enumerate(zip(got4, want)) if a != b))
+        m3.close()
 
 
 _DEFER_SPECS = {
