@@ -789,23 +789,34 @@ __device__ __forceinline__ void attn_group_partial(const float* q_g, const float
     }
   }
   __syncthreads();
+  // branch-free reader (threads past the group's KVM * hs outputs read head 0, element 0; their results are never
+  // used): all 24 LDS reads leave before the first is consumed - behind a mask the compiler made three round trips of
+  // them, and inside an unrolled loop it makes one per iteration (see attn_fast_partial)
   float r = 0.f, L = 0.f, M2 = -INFINITY;
-  if (tid < KVM * hs) {
-    const int j = tid / hs, e = tid - j * hs;
-    float mv[KH_WAVES_MAX];
+  {
+    const bool mine = tid < KVM * hs;
+    const int j = mine ? tid / hs : 0, e = mine ? tid - j * hs : 0;
+    float mv[KH_WAVES_MAX], lv[KH_WAVES_MAX], ov[KH_WAVES_MAX];
 #pragma unroll
     for (int w = 0; w < KH_WAVES_MAX; ++w) {
-      mv[w] = w < nw ? red[w * KVM + j] : -INFINITY;  // words of absent waves were never written
+      const int wc = w < nw ? w : 0;  // words of absent waves were never written
+      mv[w] = red[wc * KVM + j];
+      lv[w] = lpart[wc * KVM + j];
+      ov[w] = opart[(size_t)(wc * KVM + j) * hs + e];
+    }
+#pragma unroll
+    for (int w = 0; w < KH_WAVES_MAX; ++w) {
+      mv[w] = w < nw ? mv[w] : -INFINITY;
       M2 = fmaxf(M2, mv[w]);
     }
     // M2 is finite: every split owns a valid timestep (use_batch's precondition)
 #pragma unroll
     for (int w = 0; w < KH_WAVES_MAX; ++w) {
-      const int wc = w < nw ? w : 0;
       const float c = __builtin_amdgcn_exp2f(mv[w] - M2);  // 0 for a wave without a timestep / an absent wave
-      r = __builtin_fmaf(c, opart[(size_t)(wc * KVM + j) * hs + e], r);
-      L = __builtin_fmaf(c, lpart[wc * KVM + j], L);
+      r = __builtin_fmaf(c, ov[w], r);
+      L = __builtin_fmaf(c, lv[w], L);
     }
+    if (!mine) M2 = -INFINITY;
   }
   r_out = r;
   L_out = L;
