@@ -201,6 +201,14 @@ int main(int argc, char** argv) {
     FFN_RINGS(1, 4, 256, 1024, false, 0, 1);
     FFN_RINGS(2, 4, 512, 256, false, 0, 1);
     FFN_RINGS(2, 4, 512, 512, false, 0, 1);
+    // [r6] four waves per CU: 11008 pairs over 1024 waves = 10 or 11 items each (2.3 % static imbalance instead of the
+    // 11.6 % of 5 or 6 items at eight waves per CU, profiles/r6_mb_skew.txt), the bytes in flight made up by the ring depth
+    FFN_RINGS(4, 4, 256, 256, false, 0, 1);
+    FFN_RINGS(6, 4, 256, 256, false, 0, 1);
+    FFN_RINGS(8, 4, 256, 256, false, 0, 1);
+    FFN_RINGS(12, 4, 256, 256, false, 0, 1);
+    FFN_RINGS(4, 4, 256, 256, true, 0, 1);
+    FFN_RINGS(8, 4, 256, 256, true, 0, 1);
     if (g_more) {
       FFN_RINGX(2, 4, 256, 512, true, 0);     // control: blocked mapping alone, same 8 waves per CU (43 items -> 6 rounds)
       FFN_RINGX(2, 4, 704, 256, true, 256);   // 11 waves per CU: 43 items = 10 x 4 + 3
