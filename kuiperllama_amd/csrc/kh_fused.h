@@ -318,19 +318,21 @@ struct CombStager {
     for (int s0 = 0;;) {
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
-        // no `if (s0 + u < nact)` [r6]: a slot past nact has f = 0 and L = 0 (written above) and a clamped, finite o
-        // (load_batch), so its terms add exact zeros, and the LDS reads of a batch leave together instead of one
-        // round trip per split (kh_attn.h::attn_merge_lds); s0 + u <= 15 because SB divides 16
+        // (the per-split branch stays HERE, unlike in kh_attn.h::attn_merge_lds: without it the compiler hoists every
+        // factor read of the batch, the 4-float4 instantiations cross their 128 registers and spill 20-24 bytes of
+        // scratch - and the launch gained nothing, profiles/r6_attn_merge_bf_ab.txt)
+        if (s0 + u < nact) {  // uniform
 #pragma unroll
-        for (int v = 0; v < MAXV; ++v) {
-          const float f = fl[hb[v] + s0 + u];
-          const float l = fl[nf + hb[v] + s0 + u];
-          const f32x4 t = ov[u * MAXV + v];
-          num[v].x = __builtin_fmaf(t.x, f, num[v].x);
-          num[v].y = __builtin_fmaf(t.y, f, num[v].y);
-          num[v].z = __builtin_fmaf(t.z, f, num[v].z);
-          num[v].w = __builtin_fmaf(t.w, f, num[v].w);
-          den[v] = __builtin_fmaf(l, f, den[v]);
+          for (int v = 0; v < MAXV; ++v) {
+            const float f = fl[hb[v] + s0 + u];
+            const float l = fl[nf + hb[v] + s0 + u];
+            const f32x4 t = ov[u * MAXV + v];
+            num[v].x = __builtin_fmaf(t.x, f, num[v].x);
+            num[v].y = __builtin_fmaf(t.y, f, num[v].y);
+            num[v].z = __builtin_fmaf(t.z, f, num[v].z);
+            num[v].w = __builtin_fmaf(t.w, f, num[v].w);
+            den[v] = __builtin_fmaf(l, f, den[v]);
+          }
         }
       }
       s0 += SB;
